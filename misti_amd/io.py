@@ -1,0 +1,276 @@
+"""Host-side readers/writers for the text formats either side of the hot path.
+
+These mirror the behaviour of the reference's ``migrationIO.py`` for the file
+formats MiSTI consumes and produces (cites are ``/root/reference`` file:line):
+
+  * PSMC output  -> merged two-genome time grid   (ReadPSMCFile :183-222, ReadPSMC :224-295)
+  * units file   -> scaling constants              (Units :100-176)
+  * JSFS file    -> rows of 8 numbers              (ReadJAFS :557-608, PrintJAFSFile :526-554)
+  * bootstrap resampling of JSFS chunks            (BootstrapJAFS :506-524)
+  * ``#MiSTI2 ver 0.4`` result file                (OutputMigration :346-375)
+
+Everything here is microsecond-scale text handling on the host; none of it is
+on the likelihood hot path.
+"""
+from __future__ import annotations
+
+import io as _io
+import random
+from dataclasses import dataclass, field
+
+import numpy as np
+
+JSFS_COLUMNS = ["total", "0100", "1100", "0001", "0101", "1101", "0011", "0111"]
+
+
+class FormatError(ValueError):
+    """A malformed input file (the reference prints and calls sys.exit(0))."""
+
+
+@dataclass
+class Units:
+    """Scaling constants; defaults of migrationIO.Units (:101-107).
+
+    Unlike the reference (class-level mutable state) this is an ordinary value.
+    """
+    mutRate: float = 1.25e-8
+    binsize: float = 100
+    N0: float = 10000
+    genTime: float = 1
+    hetloss1: float = 0.0
+    hetloss2: float = 0.0
+
+    @classmethod
+    def from_file(cls, fn, **kw):
+        """``key=value`` lines, unknown keys ignored, missing file -> defaults (:146-176)."""
+        u = cls(**kw)
+        try:
+            with open(fn) as f:
+                for line in f:
+                    parts = line.split("=")
+                    if len(parts) != 2 or parts[0] not in ("mutRate", "binsize", "N0", "genTime"):
+                        continue
+                    try:
+                        setattr(u, parts[0], float(parts[1]))
+                    except ValueError:
+                        print("Cannot read %s entry from file, using default or previous values" % parts[0])
+        except OSError:
+            print("Units input file not found, using default values.")
+        return u
+
+    def set_hetloss(self, hl):                                   # SetHetLoss :129-141
+        for name, v in zip(("hetloss1", "hetloss2"), hl):
+            if v is None:
+                continue
+            if not (0.0 <= v < 1.0):
+                raise FormatError("Hetloss should be between 0 and 1.")
+            setattr(self, name, float(v))
+
+    def describe(self):                                          # PrintUnits :143-144
+        return ("Units: mutation rate = %s \tbinsize = %s \tN0 = %s \tgeneration time = %s"
+                % (self.mutRate, self.binsize, self.N0, self.genTime))
+
+
+@dataclass
+class InputData:
+    """What ReadPSMC returns (migrationIO.InputData :46-58)."""
+    times: list            # numT-1 interval lengths, coalescent units
+    lambdas: list          # numT pairs of coalescence rates
+    scaleTime: float
+    theta: float
+    divergenceTime: float = -1
+    scaleEPS: float = 1.0
+    rho: float | None = None
+    sampleDateDiscr: int = 0
+    Tpsmc: list = field(default_factory=list)
+
+
+def read_psmc_file(src, rd=-1):
+    """One PSMC output -> (times, sizes, round, theta, rho).  ReadPSMCFile :183-222.
+
+    ``src`` is a path or a file-like object.  The last ``RD`` round is used when
+    ``rd`` is -1 or exceeds the number of rounds.
+    """
+    if hasattr(src, "read"):
+        lines = src.read().splitlines()
+    else:
+        with open(src) as f:
+            lines = f.read().splitlines()
+    rows = [l.split() for l in lines]
+    if any(len(r) == 0 for r in rows):
+        raise FormatError("blank line in PSMC file")          # reference: IndexError
+    rounds = [int(r[1]) for r in rows if r[0] == "RD"]
+    if not rounds:
+        raise FormatError("Corrupted or empty input file")
+    last = rounds[-1]                                            # reference keeps the last seen
+    if rd == -1 or rd > last:
+        rd = last
+    start = next(i for i, r in enumerate(rows) if r[0] == "RD" and int(r[1]) == rd)
+    th = rh = 0.0
+    i = start
+    while rows[i][0] != "RS":
+        if rows[i][0] == "TR":
+            th, rh = float(rows[i][1]), float(rows[i][2])
+        i += 1
+        if i >= len(rows):
+            raise FormatError("no RS rows after RD %d" % rd)
+    tk, lk = [], []
+    while rows[i][0] != "PA":
+        if rows[i][0] != "RS":
+            raise FormatError("Unexpected line.")
+        tk.append(float(rows[i][2]))
+        lk.append(float(rows[i][3]))
+        i += 1
+        if i >= len(rows):
+            raise FormatError("PSMC round not terminated by a PA line")
+    return tk, lk, rd, th, rh
+
+
+def merge_psmc(d1, d2, sample_date=0.0, units=None):
+    """Two parsed PSMC trajectories -> InputData on the merged grid.  ReadPSMC :224-295."""
+    u = units or Units()
+    theta = 4.0 * u.binsize * u.mutRate * u.N0
+    scale_time = 2 * u.genTime * u.N0
+    th1 = d1[3] / (1.0 - u.hetloss1)
+    th2 = d2[3] / (1.0 - u.hetloss2)
+    t1 = [v * th1 / theta for v in d1[0]]
+    e1 = [v * th1 / theta for v in d1[1]]
+    t2 = [v * th2 / theta for v in d2[0]]
+    e2 = [v * th2 / theta for v in d2[1]]
+    sd = sample_date / 2 / u.N0 / u.genTime
+    if sd > 0:                                                   # ancient second genome :244-248
+        t2 = [0.0] + [v + sd for v in t2]
+        e2 = [1.0] + e2
+    grid = sorted(t1 + t2[1:])
+    try:
+        sample_discr = grid.index(sd)
+    except ValueError:
+        raise FormatError("sample date is not a point of the merged grid")
+
+    def rates_on_grid(t, e):
+        # rate of the genome's interval that contains each merged grid point
+        idx = np.searchsorted(np.asarray(t[1:]), np.asarray(grid), side="right")
+        idx = np.minimum(idx, len(e) - 1)
+        own = [0] + [int(np.searchsorted(np.asarray(grid), v, side="left")) for v in t[1:]] + [len(grid)]
+        return [1.0 / e[i] for i in idx], own
+
+    l1, own1 = rates_on_grid(t1, e1)
+    l2, own2 = rates_on_grid(t2, e2)
+    lam = [[a, b] for a, b in zip(l1, l2)]
+    dt = [b - a for a, b in zip(grid[:-1], grid[1:])]
+    return InputData(dt, lam, scale_time, theta, scaleEPS=1, rho=d1[4] * theta / th1,
+                     sampleDateDiscr=sample_discr, Tpsmc=[own1, own2])
+
+
+def read_psmc(fn1, fn2, sample_date=0.0, rd=-1, units=None):
+    return merge_psmc(read_psmc_file(fn1, rd), read_psmc_file(fn2, rd), sample_date, units)
+
+
+# ---------------------------------------------------------------- JSFS ----
+def read_jsfs(src):
+    """JSFS file (format version >= 1) -> (rows, pop1, pop2).  ReadJAFS :557-608."""
+    if hasattr(src, "read"):
+        lines = src.read().split("\n")
+    else:
+        with open(src) as f:
+            lines = f.read().split("\n")
+    if lines and lines[-1] == "":
+        lines.pop()
+    if not lines or not lines[0].startswith("#MiSTI_JSFS"):
+        raise FormatError("Corrupted JSFS file header.")
+    pars = lines[0].split(" ")
+    if len(pars) < 3 or float(pars[2]) < 1:
+        raise FormatError("The file version is not supported anymore.")
+    pop1 = pop2 = None
+    i = 0
+    while i < len(lines) and lines[i].startswith("#"):
+        tag = lines[i][1:5]
+        if tag in ("pop1", "pop2"):
+            p = lines[i].split("\t")
+            if len(p) != 2:
+                raise FormatError("Corrupted JSFS file header.")
+            if tag == "pop1":
+                pop1 = p[1]
+            else:
+                pop2 = p[1]
+        i += 1
+    if i < len(lines) and lines[i].startswith("total"):
+        i += 1
+    rows = []
+    for line in lines[i:]:
+        cols = line.split("\t")
+        if len(cols) != 8:
+            raise FormatError("Unexpected line. Expected an entry for JSFS with eight TAB-separated columns.")
+        rows.append([float(v) for v in cols])
+    return rows, pop1, pop2
+
+
+def format_jsfs(rows, pop1=None, pop2=None):
+    """Rows (7 or 8 numbers each) -> JSFS file text.  PrintJAFSFile :526-554."""
+    out = ["#MiSTI_JSFS version 1.0"]
+    if pop1:
+        out.append("#pop1\t" + pop1.strip("\n\r"))
+    if pop2:
+        out.append("#pop2\t" + pop2.strip("\n\r"))
+    out.append("\t".join(JSFS_COLUMNS))
+    if rows and not isinstance(rows[0], (list, tuple, np.ndarray)):
+        rows = [rows]
+    for r in rows:
+        r = list(r)
+        if len(r) == 7:
+            r = [sum(r)] + r
+        if len(r) != 8:
+            raise FormatError("Unexpected SFS entry.")
+        out.append("\t".join(str(v) for v in r))
+    return "\n".join(out) + "\n"
+
+
+def bootstrap_jsfs(rows, rng=None, normalize=False):
+    """Resample chunk rows with replacement up to the genome length.  BootstrapJAFS :506-524."""
+    rng = rng or random
+    if any(len(r) != 8 for r in rows):
+        raise FormatError("Cannot use provided SFS for bootstrap.")
+    genome = sum(r[0] for r in rows)
+    seg = sum(sum(r[1:]) for r in rows)
+    sfs = [0] * 8
+    while sfs[0] < genome:
+        pick = rows[rng.randint(0, len(rows) - 1)]
+        sfs = [a + b for a, b in zip(sfs, pick)]
+    if normalize:
+        seg_bs = sum(sfs[1:])
+        sfs = [v * (seg / seg_bs) for v in sfs]
+    return sfs
+
+
+def bootstrap_table(rows, n, rng=None):
+    """Row 0 = sum of all chunks, rows 1..n = resamples (utils/generateJSFS_bs.py:39-48)."""
+    true = [sum(r[i] for r in rows) for i in range(8)]
+    return [true] + [bootstrap_jsfs(rows, rng) for _ in range(n)]
+
+
+# ------------------------------------------------------ result writer ----
+def format_migration(model, llh, scale_time=1, scale_eps=1):
+    """``#MiSTI2 ver 0.4`` text from an evaluated engine.  OutputMigration :346-369.
+
+    ``model`` needs ``times splitT sampleDate thrh JAFS dataJAFS lc lh mi Pr``.
+    """
+    acc = [sum(model.times[0:i]) for i in range(len(model.times) + 1)]
+    o = _io.StringIO()
+    o.write("#MiSTI2 ver 0.4\n")
+    o.write("LK\t%s\n" % llh)
+    o.write("ST\t%s\n" % model.splitT)
+    o.write("SD\t%s\n" % model.sampleDate)
+    o.write("TR\t%s\t%s\n" % (model.thrh[0], model.thrh[1]))
+    o.write("SFS\t" + "\t".join(map(str, model.JAFS)) + "\n")
+    tot = sum(model.dataJAFS)
+    o.write("DSF\t" + "\t".join(str(v / tot) for v in model.dataJAFS) + "\n")
+    o.write("SCT\t%s\n" % scale_time)
+    o.write("SCE\t%s\n" % scale_eps)
+    for i, t in enumerate(acc):
+        cols = [t, 1.0 / model.lc[i][0], 1.0 / model.lc[i][1], 1.0 / model.lh[i][0], 1.0 / model.lh[i][1],
+                model.mi[i][0], model.mi[i][1]]
+        if i < model.splitT:
+            for pair in model.Pr[i]:
+                cols += [pair[0], pair[1]]
+        o.write("RS\t" + "\t".join(str(v) for v in cols) + "\n")
+    return o.getvalue()

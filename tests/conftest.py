@@ -1,0 +1,36 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """Cases of tests/golden/<name>.json with the shared grids expanded."""
+    d = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    grids = d.get("grids", {})
+    for c in d["cases"]:
+        if "grid" in c["in"]:
+            g = grids[c["in"]["grid"]]
+            c["in"]["times"] = g["times"]
+            c["in"]["lambdas"] = g["lambdas"]
+    return d["cases"]
+
+
+@pytest.fixture(scope="session")
+def golden_small():
+    return load_golden("golden_small")
+
+
+@pytest.fixture(scope="session")
+def golden_synthetic():
+    return load_golden("golden_synthetic")

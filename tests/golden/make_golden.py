@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE (``/root/reference``).
+
+Runs only in the build container (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+and writes ``tests/golden/golden_*.json``: plain data - inputs of the hot path
+(interval lengths, PSMC rates, JSFS row, split time, -mi/-pu descriptors, flags,
+parameter vector) and what the reference's ``MigrationInference`` returned for
+them (llh, llh_const, expected JAFS, corrected rates ``lc``, pair-state trace
+``Pr``).  Also dumps the reference reader's ``InputData`` for synthetic PSMC
+files to pin ``misti_amd.io.read_psmc``.
+
+Reference environment: Python 3.10.12, NumPy 2.2.6 (``numpy.mat`` alias
+restored), SciPy 1.15.3.  The inputs are synthetic (``misti_amd.synth``).
+"""
+import contextlib
+import io
+import json
+import os
+import random
+import sys
+import tempfile
+import time
+
+import numpy
+
+numpy.mat = numpy.asmatrix            # NumPy >= 2 removed the alias the reference imports
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import migrationIO                     # noqa: E402  (reference)
+import MigrationInference as MI        # noqa: E402  (reference)
+from misti_amd import synth            # noqa: E402
+
+
+def run_reference(times, lambdas, sfs, split, mi, pu, kw, params):
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        m = MI.MigrationInference(list(times), [list(x) for x in lambdas], list(sfs), split,
+                                  [list(x) for x in mi], [list(x) for x in pu], **kw)
+        llh = m.JAFSLikelihood(list(params))
+    ok = bool(numpy.isfinite(llh))
+    rec = {
+        "llh": float(llh) if ok else None,
+        "llh_const": float(m.llh_const),
+        "numT": m.numT, "splitT": m.splitT,
+        "stdout": out.getvalue().strip().splitlines()[-1:] if not ok else [],
+    }
+    if ok:
+        rec["JAFS"] = [float(v) for v in m.JAFS]
+        rec["lc"] = [[float(a), float(b)] for a, b in m.lc]
+        rec["Pr"] = [[[float(c) for c in r] for r in p] for p in m.Pr]
+    return rec
+
+
+def case(name, times, lambdas, sfs, split, mi=(), pu=(), params=(), **kw):
+    t0 = time.time()
+    rec = run_reference(times, lambdas, sfs, split, mi, pu, kw, params)
+    return {"name": name,
+            "in": {"times": list(times), "lambdas": [list(x) for x in lambdas], "sfs": list(sfs),
+                   "split": split, "mi": [list(x) for x in mi], "pu": [list(x) for x in pu],
+                   "kw": kw, "params": list(params)},
+            "out": rec, "ref_seconds": round(time.time() - t0, 3)}
+
+
+def anchors():
+    """SURVEY.md appendix A."""
+    T = [0.01, 0.02, 0.04, 0.08, 0.16, 0.32, 0.64]
+    L = [[1, 2], [1, 2], [0.8, 1.5], [0.8, 1.5], [1.2, 1.0], [1.2, 1.0], [0.9, 0.9], [0.7, 0.7]]
+    S = [100000, 900, 250, 1000, 600, 400, 260, 410]
+    two = [[1, 1, 5, 0.3, 1], [2, 1, 5, 0.1, 1]]
+    c = []
+    c.append(case("A1", T, L, S, 5, smooth=True))
+    c.append(case("A2", T, L, S, 5, smooth=True, cpfit=True))
+    c.append(case("A3", T, L, S, 5, two, params=[0.3, 0.1], smooth=True, cpfit=True, unfolded=True))
+    c.append(case("A4", T, L, S, 5, two, params=[0.3, 0.1], smooth=True))
+    c.append(case("A5", T, L, S, 5, [[1, 0, 5, 0.5, 0]], [[2, 3, 0.2, 0]], trueEPS=True, unfolded=True))
+    c.append(case("A6", T, L, S, 5, [[1, 2, 5, 0.3, 0]], smooth=True, cpfit=True, sampleDate=2))
+    c.append(case("A7", T, L, S, 4.5, smooth=True, cpfit=True))
+    c.append(case("A8", T, L, S, 5, [[1, 1, 5, -0.1, 1]], params=[-0.1], smooth=True, cpfit=True))
+    c.append(case("A9", T, L, S, 5, [[2, 0, 5, 0.2, 0]], [[1, 2, 0.1, 1]], params=[0.1], cpfit=True))
+    # extra small cases: every flag combination on the literal inputs
+    c.append(case("B1", T, L, S, 5, two, params=[0.05, 0.7], cpfit=True))
+    c.append(case("B2", T, L, S, 5, two, params=[0.05, 0.7], trueEPS=True, cpfit=True, smooth=True))
+    c.append(case("B3", T, L, S, 5, two, params=[0.05, 0.7], trueEPS=True))
+    c.append(case("B4", T, L, S, 3, [[1, 0, 3, 1.5, 1]], [[1, 1, 0.3, 1]], params=[1.5, 0.3], cpfit=True, smooth=True))
+    c.append(case("B5", T, L, S, 6, [[2, 1, 4, 0.2, 0]], [[2, 4, 0.5, 0]], cpfit=True, smooth=True, unfolded=True))
+    c.append(case("B6", T, L, S, 5.25, [[1, 0, 6, 0.4, 1]], params=[0.4], cpfit=True, smooth=True))
+    c.append(case("B7", T, L, S, 5, two, params=[0.3, 0.1], smooth=True, cpfit=True, mixtureTH=0.9))
+    c.append(case("B8", T, L, S, 5, [[1, 0, 5, 0.5, 0]], [[1, 0, 1.0, 0]], cpfit=True, smooth=True, sampleDate=0))
+    c.append(case("B9", T, L, S, 5, [[1, 3, 5, 0.5, 0]], [], cpfit=True, smooth=True, sampleDate=3))
+    c.append(case("B10", T, L, S, 5, [], [[2, 5, 0.5, 0]], cpfit=True, smooth=True, sampleDate=5))
+    c.append(case("B11", T, L, S, 7, [[1, 0, 7, 0.2, 0], [2, 0, 7, 0.1, 0]], cpfit=True, smooth=True))
+    c.append(case("B12", T, L, S, 1, cpfit=True, smooth=True))
+    c.append(case("B13", T, L, S, 0, cpfit=True, smooth=True))
+    c.append(case("B14", T, L, S, 5, two, params=[30.0, 0.1], smooth=True, cpfit=True))
+    return c
+
+
+def reader_dumps(tmp):
+    """InputData as the reference's own ReadPSMC produces it, for synthetic PSMC text."""
+    out = []
+    for n1, n2, sdate, hl in [(16, 17, 0.0, None), (64, 65, 0.0, None), (64, 64, 40000.0, (0.0, 0.1)),
+                              (24, 31, 12000.0, (0.05, 0.2))]:
+        t1 = synth.psmc_text(n1, 1, synth.THETA_1, rounds=2)
+        t2 = synth.psmc_text(n2, 2, synth.THETA_2, rounds=2)
+        f1, f2 = os.path.join(tmp, "g1.psmc"), os.path.join(tmp, "g2.psmc")
+        open(f1, "w").write(t1)
+        open(f2, "w").write(t2)
+        migrationIO.Units.hetloss1, migrationIO.Units.hetloss2 = (hl or (0.0, 0.0))
+        d = migrationIO.ReadPSMC(f1, f2, sdate)
+        migrationIO.Units.hetloss1, migrationIO.Units.hetloss2 = 0.0, 0.0
+        out.append({"n1": n1, "n2": n2, "sdate": sdate, "hetloss": list(hl) if hl else None,
+                    "psmc1": t1, "psmc2": t2,
+                    "times": d.times, "lambdas": d.lambdas, "scaleTime": d.scaleTime, "theta": d.theta,
+                    "rho": d.rho, "sampleDateDiscr": d.sampleDateDiscr, "Tpsmc": d.Tpsmc})
+    return out
+
+
+def synthetic_cases():
+    """numT = 32 and numT = 128 cases shaped like BASELINE.json's configs."""
+    c = []
+    # ---- config 1: numT=32, split 20, no migration --------------------------
+    inp32 = synth.psmc_pair(16, 17)
+    t32, lh32, _ = synth.self_consistent(inp32, 20)
+    truth = case("tmp", t32, lh32, [1] * 8, 20, trueEPS=True, cpfit=True, unfolded=True)
+    sfs32 = synth.counts_from_spectrum(truth["out"]["JAFS"])
+    for nm, kw in [("default", dict(smooth=True)), ("cpfit", dict(smooth=True, cpfit=True)),
+                   ("cpfit_uf_nosmooth", dict(cpfit=True, unfolded=True)),
+                   ("trueEPS_cpfit", dict(trueEPS=True, cpfit=True, smooth=True))]:
+        c.append(case("c1_n32_" + nm, t32, lh32, sfs32, 20, **kw))
+    # raw random PSMC rates (not self-consistent): correction stress
+    c.append(case("c1_n32_rawpsmc_cpfit", inp32.times, inp32.lambdas, sfs32, 20, smooth=True, cpfit=True))
+    c.append(case("c1_n32_rawpsmc_default", inp32.times, inp32.lambdas, sfs32, 20, smooth=True))
+
+    # ---- config 2: numT=128, one band -mi 1 4 {st} {r} 1, --cpfit ------------
+    inp = synth.psmc_pair(64, 65)
+    true_split, true_rate = 64, 0.2
+    t128, lh128, _ = synth.self_consistent(inp, true_split, [[1, 4, true_split, true_rate, 0]])
+    truth = case("tmp", t128, lh128, [1] * 8, true_split, [[1, 4, true_split, true_rate, 0]],
+                 trueEPS=True, cpfit=True, unfolded=True)
+    sfs128 = synth.counts_from_spectrum(truth["out"]["JAFS"])
+    rng = random.Random(5)
+    for st in (30, 48, 60, 64, 70, 93):
+        for r in (1e-3, 0.0316, 0.2, 1.0):
+            c.append(case("c2_n128_st%d_r%g" % (st, r), t128, lh128, sfs128, st,
+                          [[1, 4, st, r, 1]], params=[r], smooth=True, cpfit=True))
+    c.append(case("c2_n128_uf", t128, lh128, sfs128, 64, [[1, 4, 64, 0.2, 1]], params=[0.2],
+                  smooth=True, cpfit=True, unfolded=True))
+    c.append(case("c2_n128_pop2", t128, lh128, sfs128, 64, [[2, 4, 64, 0.2, 1]], params=[0.37],
+                  smooth=True, cpfit=True))
+    # ---- config 3: two optimised bands ------------------------------------
+    for k in range(6):
+        p = [10 ** rng.uniform(-3, 0), 10 ** rng.uniform(-3, 0)]
+        c.append(case("c3_n128_two_bands_%d" % k, t128, lh128, sfs128, 64,
+                      [[1, 4, 64, 0.1, 1], [2, 10, 64, 0.1, 1]], params=p, smooth=True, cpfit=True))
+    c.append(case("c3_n128_two_bands_default", t128, lh128, sfs128, 64,
+                  [[1, 4, 64, 0.1, 1], [2, 10, 64, 0.1, 1]], params=[0.2, 0.05], smooth=True))
+    c.append(case("c3_n128_two_bands_trueEPS", t128, lh128, sfs128, 64,
+                  [[1, 4, 64, 0.1, 1], [2, 10, 64, 0.1, 1]], params=[0.2, 0.05], smooth=True, trueEPS=True))
+    # ---- config 4: no migration, split scan incl. fractional, replicates ---
+    t4, lh4, _ = synth.self_consistent(inp, 50)
+    truth = case("tmp", t4, lh4, [1] * 8, 50, trueEPS=True, cpfit=True, unfolded=True)
+    row = synth.counts_from_spectrum(truth["out"]["JAFS"])
+    chunks = synth.chunk_rows(row, 20)
+    from misti_amd import io as mio
+    table = mio.bootstrap_table(chunks, 4, random.Random(3))
+    for st in (20, 44.5, 50, 50.25, 77):
+        for b in (0, 2):
+            c.append(case("c4_n128_st%g_bs%d" % (st, b), t4, lh4, table[b], st, smooth=True, cpfit=True))
+    c.append(case("c4_n128_default_st50", t4, lh4, table[0], 50, smooth=True))
+    c.append(case("c4_n128_default_st44.5", t4, lh4, table[1], 44.5, smooth=True))
+    # ---- config 5: ancient second genome + hetloss, band + pulse ----------
+    inp5 = synth.psmc_pair(64, 64, sample_date=40000.0, units=mio.Units(hetloss2=0.1))
+    sd = inp5.sampleDateDiscr
+    t5, lh5, _ = synth.self_consistent(inp5, 80, [[1, sd + 2, 80, 0.15, 0]], [[2, sd + 10, 0.1, 0]])
+    truth = case("tmp", t5, lh5, [1] * 8, 80, [[1, sd + 2, 80, 0.15, 0]], [[2, sd + 10, 0.1, 0]],
+                 trueEPS=True, cpfit=True, unfolded=True, sampleDate=sd)
+    sfs5 = synth.counts_from_spectrum(truth["out"]["JAFS"])
+    for st in (70, 80, 95):
+        for r, q in ((0.05, 0.02), (0.15, 0.1), (0.6, 0.4)):
+            c.append(case("c5_n128_sd%d_st%d_r%g_q%g" % (sd, st, r, q), t5, lh5, sfs5, st,
+                          [[1, sd + 2, st, r, 1]], [[2, sd + 10, q, 1]], params=[r, q],
+                          smooth=True, cpfit=True, sampleDate=sd))
+    c.append(case("c5_n128_default", t5, lh5, sfs5, 80, [[1, sd + 2, 80, 0.15, 1]], [[2, sd + 10, 0.1, 1]],
+                  params=[0.15, 0.1], smooth=True, sampleDate=sd))
+    return c
+
+
+def dedupe(cases):
+    """Store each (times, lambdas) grid once; cases refer to it by key."""
+    grids = {}
+    for c in cases:
+        key = None
+        blob = json.dumps([c["in"]["times"], c["in"]["lambdas"]])
+        for k, v in grids.items():
+            if v["_blob"] == blob:
+                key = k
+        if key is None:
+            key = "grid%d" % len(grids)
+            grids[key] = {"_blob": blob, "times": c["in"]["times"], "lambdas": c["in"]["lambdas"]}
+        del c["in"]["times"], c["in"]["lambdas"]
+        c["in"]["grid"] = key
+    for v in grids.values():
+        del v["_blob"]
+    return grids
+
+
+def main():
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        readers = reader_dumps(tmp)
+    json.dump({"generator": "tests/golden/make_golden.py", "cases": readers},
+              open(os.path.join(HERE, "golden_readers.json"), "w"))
+    a = anchors()
+    json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6",
+               "grids": dedupe(a), "cases": a},
+              open(os.path.join(HERE, "golden_small.json"), "w"))
+    s = synthetic_cases()
+    for c in s:                        # the pair-state trace is pinned by the small cases
+        c["out"].pop("Pr", None)
+    json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6",
+               "grids": dedupe(s), "cases": s},
+              open(os.path.join(HERE, "golden_synthetic.json"), "w"))
+    n_inf = sum(1 for x in a + s if x["out"]["llh"] is None)
+    print("wrote %d small + %d synthetic cases (%d -inf) in %.1f s" % (len(a), len(s), n_inf, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
