@@ -1,0 +1,177 @@
+/*
+ * misti_hip.h - C ABI of the MI355X (gfx950) composite-likelihood engine for MiSTI.
+ *
+ * Drop-in boundary.  The reference (Genomics-HSE/MiSTI, pure Python) has no FFI;
+ * its seam for this path is the Python method
+ *
+ *     MigrationInference.JAFSLikelihood(mu) -> float      MigrationInference.py:566-614
+ *
+ * together with the constructor (MigrationInference.py:41-200), SetModel /
+ * MapParameters (:229-298) and SetJAFS (:202-227).  The entry points below are
+ * what a ctypes binding for that seam binds (see INTEGRATION.md for the stub a
+ * maintainer would add to MigrationInference.py).  One call evaluates a BATCH of
+ * candidates (split time, migration-band rates, pulse rates) x bootstrap JSFS
+ * replicates; the reference evaluates one (candidate, replicate) per call and
+ * fans out over OS processes (README.md:110-115, test.bs/ scripts).
+ *
+ * Conventions
+ *   - plain C types only; every buffer is caller-allocated, C-contiguous;
+ *     the library copies what it needs and keeps no caller pointer after return;
+ *   - every function returns 0 on success or a negative MISTI_E_* code and never
+ *     calls exit() or lets a C++ exception cross the ABI; misti_last_error()
+ *     gives the message of the last failure on the calling thread;
+ *   - a context is used by one host thread at a time; work is issued on one HIP
+ *     stream per context (replaceable with misti_set_stream);
+ *   - there is NO CPU fallback: without a HIP device misti_create fails.
+ */
+#ifndef MISTI_HIP_H
+#define MISTI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISTI_ABI_VERSION 1
+
+/* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
+#define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */
+#define MISTI_TRUE_EPS  2u   /* trueEPS=True  (MiSTI.py --trueEPS)          */
+#define MISTI_SMOOTH    4u   /* smooth=True   (MiSTI.py default; --nosmooth clears) */
+#define MISTI_UNFOLDED  8u   /* unfolded=True (MiSTI.py -uf)                */
+
+/* error codes */
+#define MISTI_E_ARG      (-1)  /* invalid argument / model                  */
+#define MISTI_E_HIP      (-2)  /* HIP runtime error                         */
+#define MISTI_E_NODEV    (-3)  /* no usable HIP device                      */
+#define MISTI_E_LIMIT    (-4)  /* size beyond a compiled-in limit           */
+
+/* per-candidate status (the reference prints a line and returns -inf, or exits) */
+#define MISTI_OK             0
+#define MISTI_NEG_PARAM      1  /* "Hit negative value of migration rate"   :569-572 */
+#define MISTI_CORR_FAILED    2  /* "Lambda correction failed"               :346-348,576-578 */
+#define MISTI_INF_COAL       3  /* two-population last interval (:475-476 and splitT == numT) */
+#define MISTI_BAD_STRUCTURE  4  /* band/pulse/split inconsistent for this candidate (reference: PrintError + exit) */
+#define MISTI_NUMERIC        5  /* non-finite intermediate / iteration cap  */
+#define MISTI_STIFF          6  /* an interval with rate x length > 128 (a runaway corrected rate): beyond the
+                                   vector-series path; the reference's own result there is conditioned ~1e-8 */
+
+#define MISTI_MAX_BANDS   8
+#define MISTI_MAX_PULSES  8
+#define MISTI_MAX_PARAMS  16
+#define MISTI_MAX_NUMT    255   /* numT + 1 <= 256 (four 64-lane passes of the smoothing step) */
+
+/* One -mi option: MiSTI.py:63, MigrationInference.SetModel :236-258.
+ * start/end are indices into the candidate's interval grid (after the extra
+ * interval of a fractional split has been inserted, as in the reference).
+ * end == -1 means "the candidate's split index" (test.bs/san_sar.bs.sh:36:
+ * `-mi 1 4 ${st} ...`).  param >= 0 selects params[param] of the candidate
+ * (an optimised band, MapParameters :294-296); param == -1 uses `value`. */
+typedef struct {
+    int32_t pop;      /* 0 or 1  (= reference index 1 or 2, source population) */
+    int32_t start;
+    int32_t end;
+    int32_t param;
+    double  value;
+} misti_band_t;
+
+/* One -pu option: MiSTI.py:65, SetModel :259-279, MapParameters :297-298. */
+typedef struct {
+    int32_t pop;
+    int32_t time;     /* interval index */
+    int32_t param;
+    int32_t _pad;
+    double  value;
+} misti_pulse_t;
+
+/* Everything MigrationInference.__init__ receives apart from the per-candidate
+ * split time and the data JSFS. */
+typedef struct {
+    int32_t numT;          /* number of rate intervals; `times` has numT-1 entries (:102-107) */
+    int32_t sample_date;   /* sampleDate kwarg: grid index of the second sample (:81-83)       */
+    uint32_t flags;        /* MISTI_CPFIT | MISTI_TRUE_EPS | MISTI_SMOOTH | MISTI_UNFOLDED       */
+    int32_t n_band;
+    int32_t n_pulse;
+    int32_t n_param;       /* length of a candidate's parameter vector (optMis + optPus, :288-293) */
+    double  mixture_th;    /* mixtureTH kwarg (:184-185), CorrectLambda.py:267-272             */
+    const double* times;   /* [numT-1] interval lengths                                         */
+    const double* lh;      /* [numT][2] PSMC coalescence rates of genome 1 / genome 2           */
+    const misti_band_t*  bands;   /* [n_band]  */
+    const misti_pulse_t* pulses;  /* [n_pulse] */
+} misti_model_t;
+
+typedef struct misti_ctx misti_ctx;
+
+/* ---- library ------------------------------------------------------------- */
+int         misti_abi_version(void);
+const char* misti_last_error(void);
+int         misti_device_count(void);            /* HIP devices visible; <0 on error */
+
+/* ---- context = one MigrationInference "model" on one device --------------- */
+/* Replaces MigrationInference.__init__ + SetModel (:41-200, :229-289).       */
+int misti_create(const misti_model_t* model, int device, misti_ctx** out);
+int misti_destroy(misti_ctx* ctx);
+
+/* Issue work on an existing hipStream_t (e.g. PyTorch's current stream) instead
+ * of the context's own; pass NULL to go back.  The stream must belong to the
+ * context's device. */
+int misti_set_stream(misti_ctx* ctx, void* hip_stream);
+int misti_sync(misti_ctx* ctx);
+
+/* ---- batched JAFSLikelihood ----------------------------------------------- */
+/* Host-buffer form.  Replaces a loop of
+ *     m = MigrationInference(times, lh, jsfs[r], split_time[c], mi, pu, ...)   :41
+ *     llk[c][r] = m.JAFSLikelihood(params[c])                                   :566
+ * n_cand >= 0, n_rep >= 0 (n_rep == 0: spectrum only; llk may be NULL).
+ *   split_time [n_cand]            fractional allowed (:89-99)
+ *   params     [n_cand][n_param]   NULL allowed when n_param == 0
+ *   jsfs       [n_rep][8]          rows "total + 7 classes" (SetJAFS :208-211);
+ *                                  llh_const (:217-227) is computed inside
+ *   llk        [n_cand][n_rep]     -inf on a soft failure (:572,:578)
+ *   jafs       [n_cand][7]  or NULL   normalised expected spectrum (.JAFS, :583-584)
+ *   lc         [n_cand][numT+1][2] or NULL   corrected rates (.lc); row numT is used
+ *                                  only by a fractional split; unused rows = 0
+ *   pr         [n_cand][numT+2][6] or NULL   pair-state trace (.Pr, :309,:350):
+ *                                  row t = p11 g1,g2, p22 g1,g2, p12 g1,g2
+ *   status     [n_cand]     or NULL   MISTI_OK / MISTI_NEG_PARAM / ...
+ */
+int misti_eval_batch(misti_ctx* ctx, int64_t n_cand,
+                     const double* split_time, const double* params,
+                     int64_t n_rep, const double* jsfs,
+                     double* llk, double* jafs, double* lc, double* pr, int32_t* status);
+
+/* Device-buffer form: same arguments, every pointer is DEVICE memory on the
+ * context's device; asynchronous on the context's stream (call misti_sync or
+ * synchronise the stream yourself).  This is the form bench.py times. */
+int misti_eval_batch_dev(misti_ctx* ctx, int64_t n_cand,
+                         const double* d_split_time, const double* d_params,
+                         int64_t n_rep, const double* d_jsfs,
+                         double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status);
+
+/* Replicate epilogue alone: llk[c][r] from already computed spectra (device
+ * pointers).  status may be NULL (all OK).  MigrationInference.py:600-609 + :217-227. */
+int misti_llk_dev(misti_ctx* ctx, int64_t n_cand, const double* d_jafs, const int32_t* d_status,
+                  int64_t n_rep, const double* d_jsfs, double* d_llk);
+
+/* ---- measurement ----------------------------------------------------------- */
+/* When enabled, every kernel launch of this context is bracketed by HIP events
+ * on its stream.  misti_kernel_times returns the accumulated device time (ms)
+ * and launch counts since the last reset: [0] lambda-correction kernel,
+ * [1] spectrum kernel, [2] replicate (llk) kernel. */
+int misti_enable_timing(misti_ctx* ctx, int on);
+int misti_kernel_times(misti_ctx* ctx, double ms[3], int64_t launches[3], int reset);
+
+/* ---- introspection (tests) ------------------------------------------------- */
+/* Constant structure of the 44-state chain as the library derived it:
+ *   gen[4][44][44]  integer coefficient patterns A0, A1 (coalescence in pop 0/1),
+ *                   B0, B1 (migration out of pop 0/1): M = la0*A0+la1*A1+mu0*B0+mu1*B1
+ *                   (TwoPopulations.UpdateMatrixCol :336-359), row = destination
+ *   jaf[44][7]      StateToJAF (:188-219)
+ * Either pointer may be NULL. */
+int misti_tables(int32_t* gen, int32_t* jaf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTI_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libmisti_hip.so (C ABI: include/misti_hip.h).
+
+The library is the only compute path.  If it is missing or no HIP device is
+usable, every compute entry point raises - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+CPFIT, TRUE_EPS, SMOOTH, UNFOLDED = 1, 2, 4, 8
+STATUS_TEXT = {
+    0: "ok",
+    1: "Hit negative value of migration rate",
+    2: "Lambda correction failed",
+    3: "Infinite coalescent time (two populations in the last interval)",
+    4: "Split time / band / pulse structure invalid for this candidate",
+    5: "Non-finite intermediate or iteration cap",
+    6: "Stiff interval (rate x length > 128) beyond the series path",
+}
+MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
+
+
+class Band(C.Structure):
+    _fields_ = [("pop", C.c_int32), ("start", C.c_int32), ("end", C.c_int32), ("param", C.c_int32), ("value", C.c_double)]
+
+
+class Pulse(C.Structure):
+    _fields_ = [("pop", C.c_int32), ("time", C.c_int32), ("param", C.c_int32), ("_pad", C.c_int32), ("value", C.c_double)]
+
+
+class Model(C.Structure):
+    _fields_ = [("numT", C.c_int32), ("sample_date", C.c_int32), ("flags", C.c_uint32), ("n_band", C.c_int32),
+                ("n_pulse", C.c_int32), ("n_param", C.c_int32), ("mixture_th", C.c_double),
+                ("times", C.POINTER(C.c_double)), ("lh", C.POINTER(C.c_double)),
+                ("bands", C.POINTER(Band)), ("pulses", C.POINTER(Pulse))]
+
+
+class MistiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmisti_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+# every symbol include/misti_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "misti_abi_version": (C.c_int, []),
+    "misti_last_error": (C.c_char_p, []),
+    "misti_device_count": (C.c_int, []),
+    "misti_create": (C.c_int, [C.POINTER(Model), C.c_int, C.POINTER(C.c_void_p)]),
+    "misti_destroy": (C.c_int, [C.c_void_p]),
+    "misti_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "misti_sync": (C.c_int, [C.c_void_p]),
+    "misti_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_llk_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "misti_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "misti_kernel_times": (C.c_int, [C.c_void_p, _PD, C.POINTER(C.c_int64), C.c_int]),
+    "misti_tables": (C.c_int, [_PI, _PI]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building first if needed) the shared library and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise MistiError(-3, "libmisti_hip.so is not built (%s); run misti_amd.build.build()" % path)
+        _build.build()
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.misti_abi_version() != 1:
+        raise MistiError(-1, "ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise MistiError(code, load().misti_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,48 @@
+"""Build libmisti_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libmisti_hip.so")
+SOURCES = ["misti_kernels.hip", "misti_api.cpp"]
+HEADERS = ["misti_device.h", "misti_tables.hpp", "misti_consts.h", os.path.join("..", "..", "include", "misti_hip.h")]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False, extra=()):
+    """Compile the kernels and the C-ABI layer into misti_amd/csrc/libmisti_hip.so."""
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+           "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+    cmd += list(extra)
+    cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True,
+                extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else []))

@@ -1,0 +1,409 @@
+// C-ABI host layer of libmisti_hip.so (see include/misti_hip.h).
+//
+// Replaces, for a batch, what the reference does once per Python object:
+//   MigrationInference.__init__ / SetModel   MigrationInference.py:41-289   -> misti_create
+//   JAFSLikelihood                           MigrationInference.py:566-614  -> misti_eval_batch*
+// No CPU fallback: every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "misti_device.h"
+#include "misti_tables.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail(MISTI_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+const misti::HostTables& host_tables() {
+    static const misti::HostTables t = misti::build_tables();
+    return t;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct misti_ctx {
+    int device = 0;
+    misti::DevModel dm{};
+    int unfolded = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf model_f64, model_i32;        // times | lh ; run_start | run_end
+    DevBuf consts;                      // llh_const per replicate
+    DevBuf ws_jafs, ws_status, ws_lc;   // spectra / status / corrected rates when the caller passes NULL
+    DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    double ms[3] = {0, 0, 0};
+    int64_t launches[3] = {0, 0, 0};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[3];
+};
+
+namespace {
+
+// Greedy runs of (numerically) constant lh, exactly as SmoothConst scans them
+// (MigrationInference.py:387-405): a run starts at k and takes every j with
+// |lh[j] - lh[k]| < 1e-10 while j < numT-1.
+void smoothing_runs(const double* lh, int numT, int k, std::vector<int>& rs, std::vector<int>& re) {
+    rs.assign(numT, 0);
+    re.assign(numT, 0);
+    int i = 0;
+    while (i < numT) {
+        int j = i;
+        double lam = lh[2 * i + k];
+        while (j < numT - 1 && std::fabs(lh[2 * j + k] - lam) < 1e-10) ++j;
+        if (j == i) j = i + 1;                 // index numT-1: a run of its own (never smoothed: t < split <= numT-1)
+        for (int t = i; t < j; ++t) { rs[t] = i; re[t] = j; }
+        i = j;
+    }
+}
+
+int validate_model(const misti_model_t* m) {
+    if (!m) return fail(MISTI_E_ARG, "model is NULL");
+    if (m->numT < 2) return fail(MISTI_E_ARG, "numT must be >= 2 (got %d)", m->numT);
+    if (m->numT > MISTI_MAX_NUMT) return fail(MISTI_E_LIMIT, "numT %d exceeds MISTI_MAX_NUMT %d", m->numT, MISTI_MAX_NUMT);
+    if (!m->times || !m->lh) return fail(MISTI_E_ARG, "times / lh is NULL");
+    if (m->n_band < 0 || m->n_band > MISTI_MAX_BANDS) return fail(MISTI_E_LIMIT, "n_band %d out of range", m->n_band);
+    if (m->n_pulse < 0 || m->n_pulse > MISTI_MAX_PULSES) return fail(MISTI_E_LIMIT, "n_pulse %d out of range", m->n_pulse);
+    if (m->n_param < 0 || m->n_param > MISTI_MAX_PARAMS) return fail(MISTI_E_LIMIT, "n_param %d out of range", m->n_param);
+    if ((m->n_band && !m->bands) || (m->n_pulse && !m->pulses)) return fail(MISTI_E_ARG, "bands / pulses is NULL");
+    if (m->sample_date < 0 || m->sample_date >= m->numT) return fail(MISTI_E_ARG, "sample_date %d out of range", m->sample_date);
+    for (int t = 0; t < m->numT - 1; ++t)
+        if (!(m->times[t] >= 0) || !std::isfinite(m->times[t])) return fail(MISTI_E_ARG, "times[%d] is negative or not finite", t);
+    for (int t = 0; t < 2 * m->numT; ++t)
+        if (!(m->lh[t] > 0) || !std::isfinite(m->lh[t])) return fail(MISTI_E_ARG, "lh[%d] must be positive and finite", t);
+    for (int b = 0; b < m->n_band; ++b) {
+        const misti_band_t& B = m->bands[b];
+        // SetModel, MigrationInference.py:237-247
+        if (B.pop != 0 && B.pop != 1) return fail(MISTI_E_ARG, "band %d: population index should be 1 or 2", b);
+        if (B.start < m->sample_date) return fail(MISTI_E_ARG, "band %d: migration start (%d) should be >= sample date (%d)", b, B.start, m->sample_date);
+        if (B.end != -1 && B.end <= B.start) return fail(MISTI_E_ARG, "band %d: migration start (%d) should be strictly less than migration end (%d)", b, B.start, B.end);
+        if (B.end > m->numT + 1) return fail(MISTI_E_ARG, "band %d: end %d beyond the grid", b, B.end);
+        if (B.param < -1 || B.param >= m->n_param) return fail(MISTI_E_ARG, "band %d: param index %d out of range", b, B.param);
+        if (B.param < 0 && !(B.value >= 0)) return fail(MISTI_E_ARG, "band %d: fixed rate must be >= 0", b);
+        for (int c = 0; c < b; ++c) {                                   // :254-255 overlap
+            const misti_band_t& C = m->bands[c];
+            if (C.pop != B.pop) continue;
+            int be = B.end < 0 ? INT32_MAX : B.end, ce = C.end < 0 ? INT32_MAX : C.end;
+            if (B.start < ce && C.start < be) return fail(MISTI_E_ARG, "bands %d and %d: migration rate intervals should not overlap", c, b);
+        }
+    }
+    for (int p = 0; p < m->n_pulse; ++p) {
+        const misti_pulse_t& P = m->pulses[p];
+        // :260-277
+        if (P.pop != 0 && P.pop != 1) return fail(MISTI_E_ARG, "pulse %d: population index should be 1 or 2", p);
+        if (P.time < m->sample_date) return fail(MISTI_E_ARG, "pulse %d: time (%d) should be >= sample date (%d)", p, P.time, m->sample_date);
+        if (P.time >= m->numT + 1) return fail(MISTI_E_ARG, "pulse %d: time %d beyond the grid", p, P.time);
+        if (P.param < -1 || P.param >= m->n_param) return fail(MISTI_E_ARG, "pulse %d: param index %d out of range", p, P.param);
+        if (P.param < 0 && !(P.value >= 0 && P.value <= 1)) return fail(MISTI_E_ARG, "pulse %d: pulse migration rate should be between 0 and 1", p);
+        for (int c = 0; c < p; ++c)
+            if (m->pulses[c].time == P.time) return fail(MISTI_E_ARG, "pulses %d and %d: only single-direction pulse migration at a time", c, p);
+    }
+    return 0;
+}
+
+int record_begin(misti_ctx* c, int which, hipEvent_t* a, hipEvent_t* b) {
+    if (!c->timing) return 0;
+    HIP_TRY(hipEventCreate(a));
+    HIP_TRY(hipEventCreate(b));
+    HIP_TRY(hipEventRecord(*a, c->stream));
+    (void)which;
+    return 0;
+}
+int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
+    if (!c->timing) return 0;
+    HIP_TRY(hipEventRecord(b, c->stream));
+    c->pending[which].push_back({a, b});
+    return 0;
+}
+
+int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int64_t n_rep, const double* d_jsfs,
+            double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status) {
+    if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_cand == 0) return 0;
+    if (!d_split) return fail(MISTI_E_ARG, "split_time is NULL");
+    if (c->dm.n_param > 0 && !d_params) return fail(MISTI_E_ARG, "params is NULL but the model has %d parameters", c->dm.n_param);
+    if (n_rep > 0 && (!d_jsfs || !d_llk)) return fail(MISTI_E_ARG, "jsfs / llk is NULL with n_rep > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!d_jafs) { HIP_TRY(c->ws_jafs.reserve((size_t)n_cand * 7 * sizeof(double))); d_jafs = c->ws_jafs.as<double>(); }
+    if (!d_status) { HIP_TRY(c->ws_status.reserve((size_t)n_cand * sizeof(int32_t))); d_status = c->ws_status.as<int32_t>(); }
+    if (!d_lc) { HIP_TRY(c->ws_lc.reserve((size_t)n_cand * (c->dm.numT + 1) * 2 * sizeof(double))); d_lc = c->ws_lc.as<double>(); }
+    hipEvent_t a = nullptr, b = nullptr;
+    if (int r = record_begin(c, 0, &a, &b)) return r;
+    HIP_TRY(misti::launch_correct(c->dm, n_cand, d_split, d_params, d_lc, d_pr, d_status, c->stream));
+    if (int r = record_end(c, 0, a, b)) return r;
+    if (c->timing) c->launches[0] += 1;
+    if (int r = record_begin(c, 1, &a, &b)) return r;
+    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_split, d_params, d_lc, d_jafs, d_status, c->stream));
+    if (int r = record_end(c, 1, a, b)) return r;
+    if (c->timing) c->launches[1] += 1;
+    if (n_rep > 0) {
+        HIP_TRY(c->consts.reserve((size_t)n_rep * sizeof(double)));
+        HIP_TRY(misti::launch_llh_const(n_rep, d_jsfs, c->consts.as<double>(), c->unfolded, c->stream));
+        if (int r = record_begin(c, 2, &a, &b)) return r;
+        HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, c->consts.as<double>(), d_llk, c->unfolded, c->stream));
+        if (int r = record_end(c, 2, a, b)) return r;
+        if (c->timing) c->launches[2] += 1;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int misti_abi_version(void) { return MISTI_ABI_VERSION; }
+
+const char* misti_last_error(void) { return g_err.c_str(); }
+
+int misti_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(MISTI_E_NODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    return n;
+}
+
+int misti_tables(int32_t* gen, int32_t* jaf) {
+    try {
+        const misti::HostTables& t = host_tables();
+        if (gen)
+            for (int k = 0; k < 4; ++k) for (int d = 0; d < misti::NS2; ++d) for (int s = 0; s < misti::NS2; ++s)
+                gen[(k * misti::NS2 + d) * misti::NS2 + s] = t.gen[k][d][s];
+        if (jaf)
+            for (int s = 0; s < misti::NS2; ++s) for (int c = 0; c < 7; ++c) jaf[s * 7 + c] = t.jaf[s][c];
+    } catch (const std::exception& e) {
+        return fail(MISTI_E_ARG, "table construction failed: %s", e.what());
+    }
+    return 0;
+}
+
+int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
+    if (!out) return fail(MISTI_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (int r = validate_model(model)) return r;
+    int ndev = misti_device_count();
+    if (ndev <= 0) return fail(MISTI_E_NODEV, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(MISTI_E_ARG, "device %d out of range (0..%d)", device, ndev - 1);
+    misti_ctx* c = nullptr;
+    try {
+        c = new misti_ctx();
+        const misti::HostTables& t = host_tables();
+        c->device = device;
+        HIP_TRY(hipSetDevice(device));
+        // constant tables (per device; idempotent)
+        misti::DevTables dt{};
+        std::memcpy(dt.src, t.src, sizeof dt.src);
+        std::memcpy(dt.kind, t.kind, sizeof dt.kind);
+        std::memcpy(dt.mult, t.mult, sizeof dt.mult);
+        std::memcpy(dt.dcnt, t.dcnt, sizeof dt.dcnt);
+        for (int cl = 0; cl < 7; ++cl) {
+            for (int s = 0; s < 64; ++s) dt.jaf[cl][s] = s < misti::NS2 ? t.jaf[s][cl] : 0;
+            for (int s = 0; s < misti::NS1; ++s) dt.jaf1[cl][s] = t.jaf1[s][cl];
+        }
+        std::memcpy(dt.grp_lo, t.grp_lo, sizeof dt.grp_lo);
+        std::memcpy(dt.grp_hi, t.grp_hi, sizeof dt.grp_hi);
+        std::memcpy(dt.anc_n, t.anc_n, sizeof dt.anc_n);
+        std::memcpy(dt.anc_dst, t.anc_dst, sizeof dt.anc_dst);
+        std::memcpy(dt.anc_src, t.anc_src, sizeof dt.anc_src);
+        std::memcpy(dt.pulse_n, t.pulse_n, sizeof dt.pulse_n);
+        std::memcpy(dt.pulse_src, t.pulse_src, sizeof dt.pulse_src);
+        std::memcpy(dt.pulse_ab, t.pulse_ab, sizeof dt.pulse_ab);
+        HIP_TRY(misti::upload_tables(dt));
+        // the closed form after the split assumes this one-population generator
+        static const int want1[8][8] = {{-6, 0, 0, 0, 0, 0, 0, 0}, {1, -3, 0, 0, 0, 0, 0, 0}, {4, 0, -3, 0, 0, 0, 0, 0}, {1, 0, 0, -3, 0, 0, 0, 0},
+                                        {0, 2, 1, 0, -1, 0, 0, 0}, {0, 0, 1, 2, 0, -1, 0, 0}, {0, 1, 0, 1, 0, 0, -1, 0}, {0, 0, 1, 0, 0, 0, 0, -1}};
+        for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j)
+            if (t.gen1[i][j] != want1[i][j]) { delete c; return fail(MISTI_E_ARG, "one-population generator mismatch at (%d,%d)", i, j); }
+
+        const int numT = model->numT;
+        HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        std::vector<double> f64((size_t)(numT - 1) + 2 * (size_t)numT);
+        std::memcpy(f64.data(), model->times, sizeof(double) * (numT - 1));
+        std::memcpy(f64.data() + (numT - 1), model->lh, sizeof(double) * 2 * numT);
+        HIP_TRY(c->model_f64.reserve(f64.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(c->model_f64.p, f64.data(), f64.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<int> runs(4 * (size_t)numT), rs, re;
+        for (int k = 0; k < 2; ++k) {
+            smoothing_runs(model->lh, numT, k, rs, re);
+            std::memcpy(runs.data() + k * numT, rs.data(), sizeof(int) * numT);
+            std::memcpy(runs.data() + (2 + k) * numT, re.data(), sizeof(int) * numT);
+        }
+        HIP_TRY(c->model_i32.reserve(runs.size() * sizeof(int)));
+        HIP_TRY(hipMemcpy(c->model_i32.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
+        misti::DevModel& d = c->dm;
+        d.numT = numT;
+        d.sample_date = model->sample_date;
+        d.flags = model->flags;
+        d.n_band = model->n_band; d.n_pulse = model->n_pulse; d.n_param = model->n_param;
+        d.mixture_th = model->mixture_th;
+        d.times = c->model_f64.as<double>();
+        d.lh = d.times + (numT - 1);
+        d.run_start = c->model_i32.as<int>();
+        d.run_end = d.run_start + 2 * numT;
+        for (int b = 0; b < model->n_band; ++b) d.bands[b] = model->bands[b];
+        for (int p = 0; p < model->n_pulse; ++p) d.pulses[p] = model->pulses[p];
+        c->unfolded = (model->flags & MISTI_UNFOLDED) ? 1 : 0;
+    } catch (const std::exception& e) {
+        delete c;
+        return fail(MISTI_E_ARG, "misti_create: %s", e.what());
+    }
+    *out = c;
+    return 0;
+}
+
+int misti_destroy(misti_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_lc, &c->st_split, &c->st_params, &c->st_jsfs,
+                    &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
+        b->release();
+    for (int w = 0; w < 3; ++w)
+        for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return 0;
+}
+
+int misti_set_stream(misti_ctx* c, void* s) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    return 0;
+}
+
+int misti_sync(misti_ctx* c) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int misti_eval_batch_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int64_t n_rep,
+                         const double* d_jsfs, double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    return run_dev(c, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs, d_lc, d_pr, d_status);
+}
+
+int misti_llk_dev(misti_ctx* c, int64_t n_cand, const double* d_jafs, const int32_t* d_status, int64_t n_rep, const double* d_jsfs, double* d_llk) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_cand == 0 || n_rep == 0) return 0;
+    if (!d_jafs || !d_jsfs || !d_llk) return fail(MISTI_E_ARG, "jafs / jsfs / llk is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->consts.reserve((size_t)n_rep * sizeof(double)));
+    HIP_TRY(misti::launch_llh_const(n_rep, d_jsfs, c->consts.as<double>(), c->unfolded, c->stream));
+    hipEvent_t a = nullptr, b = nullptr;
+    if (int r = record_begin(c, 2, &a, &b)) return r;
+    HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, c->consts.as<double>(), d_llk, c->unfolded, c->stream));
+    if (int r = record_end(c, 2, a, b)) return r;
+    if (c->timing) c->launches[2] += 1;
+    return 0;
+}
+
+int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, int64_t n_rep, const double* jsfs,
+                     double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_cand == 0) return 0;
+    if (!split) return fail(MISTI_E_ARG, "split_time is NULL");
+    const int P = c->dm.n_param, numT = c->dm.numT;
+    if (P > 0 && !params) return fail(MISTI_E_ARG, "params is NULL but the model has %d parameters", P);
+    if (n_rep > 0 && (!jsfs || !llk)) return fail(MISTI_E_ARG, "jsfs / llk is NULL with n_rep > 0");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nc = (size_t)n_cand, nr = (size_t)n_rep;
+    HIP_TRY(c->st_split.reserve(nc * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->st_split.p, split, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (P > 0) {
+        HIP_TRY(c->st_params.reserve(nc * P * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->st_params.p, params, nc * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    if (nr) {
+        HIP_TRY(c->st_jsfs.reserve(nr * 8 * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->st_jsfs.p, jsfs, nr * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c->st_llk.reserve(nc * nr * sizeof(double)));
+    }
+    HIP_TRY(c->st_jafs.reserve(nc * 7 * sizeof(double)));
+    HIP_TRY(c->st_status.reserve(nc * sizeof(int32_t)));
+    const size_t lc_n = nc * (size_t)(numT + 1) * 2, pr_n = nc * (size_t)(numT + 2) * 6;
+    if (lc) HIP_TRY(c->st_lc.reserve(lc_n * sizeof(double)));
+    if (pr) {
+        HIP_TRY(c->st_pr.reserve(pr_n * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(c->st_pr.p, 0, pr_n * sizeof(double), c->stream));
+    }
+    int r = run_dev(c, n_cand, c->st_split.as<double>(), P > 0 ? c->st_params.as<double>() : nullptr, n_rep,
+                    nr ? c->st_jsfs.as<double>() : nullptr, nr ? c->st_llk.as<double>() : nullptr, c->st_jafs.as<double>(),
+                    lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
+    if (r) return r;
+    if (nr) HIP_TRY(hipMemcpyAsync(llk, c->st_llk.p, nc * nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (jafs) HIP_TRY(hipMemcpyAsync(jafs, c->st_jafs.p, nc * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (lc) HIP_TRY(hipMemcpyAsync(lc, c->st_lc.p, lc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pr) HIP_TRY(hipMemcpyAsync(pr, c->st_pr.p, pr_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, c->st_status.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int misti_enable_timing(misti_ctx* c, int on) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    c->timing = on != 0;
+    return 0;
+}
+
+int misti_kernel_times(misti_ctx* c, double ms[3], int64_t launches[3], int reset) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int w = 0; w < 3; ++w) {
+        for (auto& pr : c->pending[w]) {
+            HIP_TRY(hipEventSynchronize(pr.second));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+            c->ms[w] += t;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->pending[w].clear();
+        if (ms) ms[w] = c->ms[w];
+        if (launches) launches[w] = c->launches[w];
+        if (reset) { c->ms[w] = 0; c->launches[w] = 0; }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,10 @@
+// Compile-time sizes shared by the table builder, the kernels and the C-ABI layer.
+#pragma once
+namespace misti {
+constexpr int NS2 = 44;               // two-population states
+constexpr int NS1 = 8;                // one-population states
+constexpr int MAXNZ = 4;              // off-diagonal entries per generator row
+constexpr int MAXPULSE = 12;          // entries per row of the pulse operator
+constexpr int WAVES_PER_BLOCK = 4;    // candidates per 256-thread workgroup
+constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
+}  // namespace misti

@@ -1,0 +1,52 @@
+// Shared between the kernels (misti_kernels.hip) and the C-ABI host layer (misti_api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/misti_hip.h"
+
+#include "misti_consts.h"
+
+namespace misti {
+
+// Per-row view of the constant chain structure, in __constant__ memory.
+struct DevTables {
+    int src[MAXNZ][64];      // source state of the n-th off-diagonal entry of row `lane`
+    int kind[MAXNZ][64];     // 0 la0, 1 la1, 2 mu0, 3 mu1
+    int mult[MAXNZ][64];     // integer multiplicity
+    int dcnt[4][64];         // exit-rate multiplicities of the state (diagonal = -sum dcnt*rate)
+    int jaf[7][64];          // class-major StateToJAF
+    int jaf1[7][NS1];
+    int grp_lo[NS1], grp_hi[NS1];
+    int anc_n[2], anc_dst[2], anc_src[2][8];
+    int pulse_n[2][64];
+    int pulse_src[2][64][MAXPULSE];
+    int pulse_ab[2][64][MAXPULSE];
+};
+
+// Kernel-argument copy of the model (device pointers).
+struct DevModel {
+    int numT;
+    int sample_date;
+    unsigned flags;
+    int n_band, n_pulse, n_param;
+    double mixture_th;
+    const double* times;     // [numT-1]
+    const double* lh;        // [numT][2]
+    const int* run_start;    // [2][numT]  smoothing runs of constant lh (MigrationInference.py:387-405)
+    const int* run_end;      // [2][numT]
+    misti_band_t bands[MISTI_MAX_BANDS];
+    misti_pulse_t pulses[MISTI_MAX_PULSES];
+};
+
+hipError_t upload_tables(const DevTables& t);
+size_t spectrum_lds_bytes(int numT);
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+                          double* lc, double* pr, int32_t* status, hipStream_t stream);
+hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+                           const double* lc, double* jafs, int32_t* status, hipStream_t stream);
+hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
+hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
+                      const double* consts, double* llk, int unfolded, hipStream_t stream);
+
+}  // namespace misti

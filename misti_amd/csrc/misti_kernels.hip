@@ -1,0 +1,1177 @@
+// MI355X (gfx950) kernels of the MiSTI composite-likelihood engine.
+//
+// One wavefront (64 lanes) evaluates one candidate (split time, band rates, pulse
+// rates); the 44-state vector of the two-population chain lives one state per
+// lane; all per-interval rates are wave-uniform.  fp64 throughout, no MFMA (the
+// per-interval matrices are 3x3 / 44x44 with ~200 non-zeros).
+//
+// Reference path restated here (cites: /root/reference):
+//   JAFSLikelihood  MigrationInference.py:566-614     driver, status codes
+//   CorrectLambdas  MigrationInference.py:305-378     -> correct_two_pop(), post_split_rates()
+//   CorrectLambda   CorrectLambda.py:29-317           -> pair chain: pair_expv(), trf2_*()
+//   Smooth          MigrationInference.py:380-405     -> smooth_rates()
+//   JAFSpectrum     MigrationInference.py:467-540     -> spectrum_two_pop(), spectrum_one_pop()
+//   TwoPopulations / OnePopulation                     -> tables (misti_tables.hpp) + closed form
+//
+// Numerical method (differs from the reference's dense Pade expm + inverse, same
+// mathematics): exp(M T) P0 and the occupation integral  int_0^T exp(M t) P0 dt
+// (= M^-1 (P1 - P0), MigrationInference.py:538-540) are evaluated together as an
+// action on the vector by uniformisation: M T = N - q I with N >= 0, and the
+// augmented series  p_{k+1} = N p_k/(k+1),  i_{k+1} = (T p_k + q i_k)/(k+1)  whose
+// sums are P1 and the integral.  All terms are non-negative, so there is no
+// cancellation, no inverse, and the mu = 0 generator (singular: the reference
+// deletes 7 stationary states and restores their mass, TwoPopulations.py:231-309)
+// needs no special case.  After the split the chain is the Kingman coalescent in
+// rescaled time, whose 8x8 generator has eigenvalues -6,-3,-1: closed form.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "misti_device.h"
+
+namespace misti {
+
+__constant__ DevTables c_tab;
+
+// Uniformisation: one series handles q = (largest exit rate) x (interval length) up to Q_SUB
+// (exp(-Q_SUB) is far from underflow and all terms are non-negative); longer intervals are
+// cut into at most MAX_SUB equal pieces.  Cost grows like q, so q > Q_SUB * MAX_SUB is refused.
+constexpr double Q_SUB = 192.0;
+constexpr int MAX_SUB = 22;
+
+// ---------------------------------------------------------------- helpers ----
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+__device__ __forceinline__ void lds_fence() {
+    // one wave owns its LDS slice: ordering only has to be kept by the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-candidate view of the interval grid.  A fractional split time splits
+// interval s = floor(st) in two and moves the split index to s+1
+// (MigrationInference.__init__, MigrationInference.py:89-99).
+struct Grid {
+    const double* times;   // [numT0-1]
+    const double* lh;      // [numT0][2]
+    int numT0;             // intervals of the shared grid
+    int numT;              // intervals of this candidate (numT0 or numT0+1)
+    int split;             // split index of this candidate
+    int ins;               // index of the interval that was split in two, or -1
+    double frac;
+
+    __device__ __forceinline__ int src(int t) const { return (ins >= 0 && t > ins) ? t - 1 : t; }
+    __device__ __forceinline__ double T(int t) const {
+        // t in [0, numT-1)
+        if (ins < 0) return times[t];
+        if (t < ins) return times[t];
+        double whole = times[ins];
+        double t1 = frac * whole;
+        if (t == ins) return t1;
+        if (t == ins + 1) return whole - t1;
+        return times[t - 1];
+    }
+    __device__ __forceinline__ double lhk(int t, int k) const { return lh[2 * src(t) + k]; }
+};
+
+// Migration rates / pulse of interval t for this candidate
+// (SetModel + MapParameters, MigrationInference.py:229-298).
+struct Model {
+    const DevModel* m;
+    const double* par;     // [n_param] of this candidate
+    int split;
+    __device__ __forceinline__ void mig(int t, double& mu0, double& mu1) const {
+        mu0 = 0.0; mu1 = 0.0;
+        for (int b = 0; b < m->n_band; ++b) {
+            const misti_band_t& B = m->bands[b];
+            int end = B.end < 0 ? split : B.end;
+            if (t >= B.start && t < end) {
+                double v = B.param >= 0 ? par[B.param] : B.value;
+                if (B.pop == 0) mu0 = v; else mu1 = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void pulse(int t, double& pu0, double& pu1) const {
+        pu0 = 0.0; pu1 = 0.0;
+        for (int b = 0; b < m->n_pulse; ++b) {
+            const misti_pulse_t& P = m->pulses[b];
+            if (t == P.time) {
+                double v = P.param >= 0 ? par[P.param] : P.value;
+                if (P.pop == 0) pu0 = v; else pu1 = v;
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------ pair chain ----
+// Three states of one genome's two lineages: both in pop 0, both in pop 1, one
+// in each (CorrectLambda.SetMatrix, CorrectLambda.py:55-56):
+//     [ -2mu0-l0     0       mu1     ]
+//     [    0      -2mu1-l1   mu0     ]
+//     [  2mu0      2mu1    -mu0-mu1  ]
+// v <- exp(M) v by uniformisation.  Every lane carries its own (l, v); the trip
+// count is wave-uniform (bound from the largest q in the wave).
+__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], bool active, bool& guard) {
+    bool ok = isfinite(l0) && isfinite(l1);
+    if (!active || !ok) { l0 = 0.0; l1 = 0.0; }
+    double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1;
+    double q = fmax(fmax(d0, d1), fmax(d2, 0.0));            // M = N - q I with N >= 0
+    double nb = q + fmax(0.0, fmax(-l0, -l1));               // ||N||_1 (column sums q - l0, q - l1, q)
+    double nbmax = nb;
+    for (int o = 32; o > 0; o >>= 1) nbmax = fmax(nbmax, __shfl_xor(nbmax, o, 64));
+    if (!(nbmax < 1e300)) {                                  // overflowing iterate: report non-finite (TRF shrinks the step)
+        guard = true;
+        if (active) { v[0] = v[1] = v[2] = NAN; }
+        return;
+    }
+    if (nbmax > 6.0) {
+        // stiff iterate (the unbounded solver can run l up to ~1e5 when the gradient
+        // vanishes): dense scaling and squaring of the 3x3 matrix, degree-12 Taylor kernel
+        int sq = 0;
+        { double nrm = 2.0 * nbmax; while (nrm > 0.25) { nrm *= 0.5; ++sq; } }
+        double scl = ldexp(1.0, -sq);
+        double B[3][3] = {{-d0 * scl, 0.0, mu1 * scl}, {0.0, -d1 * scl, mu0 * scl}, {2.0 * mu0 * scl, 2.0 * mu1 * scl, -d2 * scl}};
+        double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        for (int k = 12; k >= 1; --k) {                      // E = I + B E / k
+            double inv = 1.0 / (double)k;
+            double Tm[3][3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+                Tm[r][c] = ((B[r][0] * E[0][c] + B[r][1] * E[1][c]) + B[r][2] * E[2][c]) * inv;
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r][c] = Tm[r][c] + (r == c ? 1.0 : 0.0);
+        }
+        for (int i = 0; i < sq; ++i) {
+            double Tm[3][3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
+                Tm[r][c] = (E[r][0] * E[0][c] + E[r][1] * E[1][c]) + E[r][2] * E[2][c];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r][c] = Tm[r][c];
+        }
+        double w0 = (E[0][0] * v[0] + E[0][1] * v[1]) + E[0][2] * v[2];
+        double w1 = (E[1][0] * v[0] + E[1][1] * v[1]) + E[1][2] * v[2];
+        double w2 = (E[2][0] * v[0] + E[2][1] * v[1]) + E[2][2] * v[2];
+        v[0] = w0; v[1] = w1; v[2] = w2;
+        if (active && !ok) { v[0] = v[1] = v[2] = NAN; }
+        return;
+    }
+    const int nsub = 1;
+    const double sc = 1.0;
+    double qs = q, nbs = nbmax;
+    double n00 = qs - d0 * sc, n11 = qs - d1 * sc, n22 = qs - d2 * sc;
+    double n02 = mu1 * sc, n12 = mu0 * sc, n20 = 2.0 * mu0 * sc, n21 = 2.0 * mu1 * sc;
+    double eq = exp(-qs);
+    for (int s = 0; s < nsub; ++s) {
+        double p0 = eq * v[0], p1 = eq * v[1], p2 = eq * v[2];
+        double a0 = p0, a1 = p1, a2 = p2;
+        double b = 1.0;                    // nbs^k / k! bounds the k-th term for every lane
+        for (int k = 1; k < 200; ++k) {
+            double inv = 1.0 / (double)k;
+            double t0 = (n00 * p0 + n02 * p2) * inv;
+            double t1 = (n11 * p1 + n12 * p2) * inv;
+            double t2 = (n20 * p0 + n21 * p1 + n22 * p2) * inv;
+            p0 = t0; p1 = t1; p2 = t2;
+            a0 += p0; a1 += p1; a2 += p2;
+            b *= nbs * inv;
+            if (b < 1e-19 && (double)k > nbs) break;
+        }
+        v[0] = a0; v[1] = a1; v[2] = a2;
+    }
+    if (active && !ok) { v[0] = v[1] = v[2] = NAN; }
+}
+
+// 3x3 inverse times vector (for the default-fit residual, CorrectLambda.py:99-107)
+__device__ __forceinline__ void solve3(const double M[3][3], const double b[3], double x[3]) {
+    double c00 = M[1][1] * M[2][2] - M[1][2] * M[2][1];
+    double c01 = M[1][2] * M[2][0] - M[1][0] * M[2][2];
+    double c02 = M[1][0] * M[2][1] - M[1][1] * M[2][0];
+    double det = M[0][0] * c00 + M[0][1] * c01 + M[0][2] * c02;
+    double id = 1.0 / det;
+    double c10 = M[0][2] * M[2][1] - M[0][1] * M[2][2];
+    double c11 = M[0][0] * M[2][2] - M[0][2] * M[2][0];
+    double c12 = M[0][1] * M[2][0] - M[0][0] * M[2][1];
+    double c20 = M[0][1] * M[1][2] - M[0][2] * M[1][1];
+    double c21 = M[0][2] * M[1][0] - M[0][0] * M[1][2];
+    double c22 = M[0][0] * M[1][1] - M[0][1] * M[1][0];
+    x[0] = (c00 * b[0] + c10 * b[1] + c20 * b[2]) * id;
+    x[1] = (c01 * b[0] + c11 * b[1] + c21 * b[2]) * id;
+    x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) * id;
+}
+
+// ------------------------------------------------------- least squares -------
+// SciPy's trust-region-reflective solver for the 2x2 systems of the
+// lambda-correction, restated so that the ITERATION SEQUENCE matches
+// scipy.optimize.least_squares(method='trf', x_scale=1, loss='linear',
+// tr_solver='exact', jac='2-point', ftol=1e-8, xtol=gtol=1e-10, max_nfev=100*n)
+// as called at CorrectLambda.py:85,260,303,305 (SciPy 1.15.3:
+// optimize/_lsq/trf.py trf_no_bounds :401-560 / trf_bounds :205-400,
+// common.py solve_lsq_trust_region :57, update_tr_radius :222, check_termination
+// :705, CL_scaling_vector :467; _numdiff.py _compute_absolute_step :146).
+// The reference's results are defined by where that iteration stops (SURVEY.md
+// section 7, hard part 1), not by the exact root.
+constexpr double LSQ_EPS = 2.220446049250313e-16;
+constexpr double LSQ_FTOL = 1e-8, LSQ_XTOL = 1e-10, LSQ_GTOL = 1e-10;
+constexpr double SQRT_EPS = 1.4901161193847656e-08;
+
+// thin SVD of an m x 2 matrix (m = 2 or 4) by one one-sided Jacobi rotation
+struct Svd2 {
+    double s[2];        // singular values, descending
+    double V[2][2];     // V[:, i] = right singular vector i  (V[r][i])
+    double uf[2];       // U^T f
+};
+template <int MROWS>
+__device__ __forceinline__ Svd2 svd_mx2(const double A[MROWS][2], const double f[MROWS]) {
+    double al = 0, be = 0, ga = 0;
+    for (int r = 0; r < MROWS; ++r) { al += A[r][0] * A[r][0]; be += A[r][1] * A[r][1]; ga += A[r][0] * A[r][1]; }
+    double c = 1.0, sn = 0.0;
+    if (ga != 0.0) {
+        double zeta = (be - al) / (2.0 * ga);
+        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        c = 1.0 / sqrt(1.0 + t * t);
+        sn = c * t;
+    }
+    double n1 = 0, n2 = 0, f1 = 0, f2 = 0;
+    for (int r = 0; r < MROWS; ++r) {
+        double a1 = c * A[r][0] - sn * A[r][1];
+        double a2 = sn * A[r][0] + c * A[r][1];
+        n1 += a1 * a1; n2 += a2 * a2; f1 += a1 * f[r]; f2 += a2 * f[r];
+    }
+    Svd2 o;
+    double s1 = sqrt(n1), s2 = sqrt(n2);
+    double v1[2] = {c, -sn}, v2[2] = {sn, c};
+    double u1 = s1 > 0 ? f1 / s1 : 0.0, u2 = s2 > 0 ? f2 / s2 : 0.0;
+    if (s1 >= s2) { o.s[0] = s1; o.s[1] = s2; o.V[0][0] = v1[0]; o.V[1][0] = v1[1]; o.V[0][1] = v2[0]; o.V[1][1] = v2[1]; o.uf[0] = u1; o.uf[1] = u2; }
+    else          { o.s[0] = s2; o.s[1] = s1; o.V[0][0] = v2[0]; o.V[1][0] = v2[1]; o.V[0][1] = v1[0]; o.V[1][1] = v1[1]; o.uf[0] = u2; o.uf[1] = u1; }
+    return o;
+}
+
+// common.py solve_lsq_trust_region :57-166 (n = 2)
+__device__ __forceinline__ void solve_tr(const Svd2& d, int m, double Delta, double& alpha, double p[2]) {
+    double suf0 = d.s[0] * d.uf[0], suf1 = d.s[1] * d.uf[1];
+    bool full_rank = (m >= 2) && (d.s[1] > LSQ_EPS * m * d.s[0]);
+    if (full_rank) {
+        double a = d.uf[0] / d.s[0], b = d.uf[1] / d.s[1];
+        p[0] = -(d.V[0][0] * a + d.V[0][1] * b);
+        p[1] = -(d.V[1][0] * a + d.V[1][1] * b);
+        if (sqrt(p[0] * p[0] + p[1] * p[1]) <= Delta) { alpha = 0.0; return; }
+    }
+    double alpha_upper = sqrt(suf0 * suf0 + suf1 * suf1) / Delta;
+    double s0s = d.s[0] * d.s[0], s1s = d.s[1] * d.s[1];
+    auto phi_fn = [&](double al, double& phi, double& dphi) {
+        double e0 = s0s + al, e1 = s1s + al;
+        double a = suf0 / e0, b = suf1 / e1;
+        double pn = sqrt(a * a + b * b);
+        phi = pn - Delta;
+        dphi = -(suf0 * suf0 / (e0 * e0 * e0) + suf1 * suf1 / (e1 * e1 * e1)) / pn;
+    };
+    double alpha_lower = 0.0;
+    if (full_rank) { double ph, dp; phi_fn(0.0, ph, dp); alpha_lower = -ph / dp; }
+    double al = alpha;
+    if (!full_rank && al == 0.0) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (al < alpha_lower || al > alpha_upper) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double ph, dp; phi_fn(al, ph, dp);
+        if (ph < 0) alpha_upper = al;
+        double ratio = ph / dp;
+        alpha_lower = fmax(alpha_lower, al - ratio);
+        al -= (ph + Delta) * ratio / Delta;
+        if (fabs(ph) < 0.01 * Delta) break;
+    }
+    double a = suf0 / (s0s + al), b = suf1 / (s1s + al);
+    p[0] = -(d.V[0][0] * a + d.V[0][1] * b);
+    p[1] = -(d.V[1][0] * a + d.V[1][1] * b);
+    double sc = Delta / sqrt(p[0] * p[0] + p[1] * p[1]);
+    p[0] *= sc; p[1] *= sc;
+    alpha = al;
+}
+
+// common.py update_tr_radius :222-245
+__device__ __forceinline__ double update_radius(double Delta, double actual, double predicted, double step_norm, bool bound_hit, double& ratio) {
+    if (predicted > 0) ratio = actual / predicted;
+    else if (predicted == 0 && actual == 0) ratio = 1.0;
+    else ratio = 0.0;
+    if (ratio < 0.25) Delta = 0.25 * step_norm;
+    else if (ratio > 0.75 && bound_hit) Delta *= 2.0;
+    return Delta;
+}
+// common.py check_termination :705-717 (0 = continue)
+__device__ __forceinline__ int check_term(double dF, double F, double dx, double xn, double ratio) {
+    bool f_ok = dF < LSQ_FTOL * F && ratio > 0.25;
+    bool x_ok = dx < LSQ_XTOL * (LSQ_XTOL + xn);
+    return (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0;
+}
+// _numdiff._compute_absolute_step :173-178 (rel_step=None, '2-point')
+__device__ __forceinline__ double fd_step(double x) { return SQRT_EPS * (x >= 0 ? 1.0 : -1.0) * fmax(1.0, fabs(x)); }
+
+// ---- bounded variant (trf_bounds, trf.py:205-400) for N = 1, 2 unknowns, lower bound
+// lb on every variable, no upper bound (CorrectLambda.py:82-86, :253-260).  The
+// residual functor is evaluated per lane (no cross-lane traffic), so different
+// lanes may run different problems (post-split refits: one interval per lane).
+template <int N> struct SvdN { double s[N]; double V[N][N]; double uf[N]; };
+
+__device__ __forceinline__ SvdN<1> svd_aug(const double A[2][1], const double f[2]) {
+    SvdN<1> o;
+    double nn = A[0][0] * A[0][0] + A[1][0] * A[1][0];
+    o.s[0] = sqrt(nn);
+    o.V[0][0] = 1.0;
+    o.uf[0] = o.s[0] > 0 ? (A[0][0] * f[0] + A[1][0] * f[1]) / o.s[0] : 0.0;
+    return o;
+}
+__device__ __forceinline__ SvdN<2> svd_aug(const double A[4][2], const double f[4]) {
+    Svd2 t = svd_mx2<4>(A, f);
+    SvdN<2> o;
+    for (int i = 0; i < 2; ++i) { o.s[i] = t.s[i]; o.uf[i] = t.uf[i]; for (int r = 0; r < 2; ++r) o.V[r][i] = t.V[r][i]; }
+    return o;
+}
+
+template <int N> __device__ __forceinline__ double vnorm(const double v[N]) {
+    double a = 0; for (int i = 0; i < N; ++i) a += v[i] * v[i]; return sqrt(a);
+}
+
+// common.py solve_lsq_trust_region :57-166, general n
+template <int N> __device__ __forceinline__ void solve_tr_n(const SvdN<N>& d, int m, double Delta, double& alpha, double p[N]) {
+    double suf[N];
+    for (int i = 0; i < N; ++i) suf[i] = d.s[i] * d.uf[i];
+    bool full_rank = (m >= N) && (d.s[N - 1] > LSQ_EPS * m * d.s[0]);
+    if (full_rank) {
+        for (int r = 0; r < N; ++r) { double a = 0; for (int i = 0; i < N; ++i) a += d.V[r][i] * (d.uf[i] / d.s[i]); p[r] = -a; }
+        if (vnorm<N>(p) <= Delta) { alpha = 0.0; return; }
+    }
+    double alpha_upper = vnorm<N>(suf) / Delta;
+    auto phi_fn = [&](double al, double& phi, double& dphi) {
+        double q[N], acc = 0;
+        for (int i = 0; i < N; ++i) { double e = d.s[i] * d.s[i] + al; q[i] = suf[i] / e; acc += suf[i] * suf[i] / (e * e * e); }
+        double pn = vnorm<N>(q);
+        phi = pn - Delta; dphi = -acc / pn;
+    };
+    double alpha_lower = 0.0;
+    if (full_rank) { double ph, dp; phi_fn(0.0, ph, dp); alpha_lower = -ph / dp; }
+    double al = alpha;
+    if (!full_rank && al == 0.0) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    for (int it = 0; it < 10; ++it) {
+        if (al < alpha_lower || al > alpha_upper) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        double ph, dp; phi_fn(al, ph, dp);
+        if (ph < 0) alpha_upper = al;
+        double ratio = ph / dp;
+        alpha_lower = fmax(alpha_lower, al - ratio);
+        al -= (ph + Delta) * ratio / Delta;
+        if (fabs(ph) < 0.01 * Delta) break;
+    }
+    for (int r = 0; r < N; ++r) { double a = 0; for (int i = 0; i < N; ++i) a += d.V[r][i] * (suf[i] / (d.s[i] * d.s[i] + al)); p[r] = -a; }
+    double sc = Delta / vnorm<N>(p);
+    for (int r = 0; r < N; ++r) p[r] *= sc;
+    alpha = al;
+}
+
+// common.py step_size_to_bound :372-398 with ub = +inf
+template <int N> __device__ __forceinline__ double step_to_bound(const double x[N], const double s[N], double lb, int hits[N]) {
+    double steps[N], mn = INFINITY;
+    for (int i = 0; i < N; ++i) {
+        steps[i] = INFINITY;
+        if (s[i] != 0) steps[i] = fmax((lb - x[i]) / s[i], s[i] > 0 ? INFINITY : -INFINITY);
+        mn = fmin(mn, steps[i]);
+    }
+    for (int i = 0; i < N; ++i) hits[i] = (steps[i] == mn) ? (s[i] > 0 ? 1 : (s[i] < 0 ? -1 : 0)) : 0;
+    return mn;
+}
+// common.py evaluate_quadratic :325-361 / build_quadratic_1d :248-299 / minimize_quadratic_1d :302-322
+template <int N> __device__ __forceinline__ double eval_quad(const double Jh[N][N], const double gh[N], const double s[N], const double diag[N]) {
+    double q = 0, l = 0;
+    for (int r = 0; r < N; ++r) { double js = 0; for (int c = 0; c < N; ++c) js += Jh[r][c] * s[c]; q += js * js; }
+    for (int i = 0; i < N; ++i) { q += s[i] * diag[i] * s[i]; l += s[i] * gh[i]; }
+    return 0.5 * q + l;
+}
+template <int N> __device__ __forceinline__ void build_quad(const double Jh[N][N], const double gh[N], const double s[N], const double diag[N],
+                                                            const double* s0, double& a, double& b, double& c) {
+    double v[N];
+    a = 0; b = 0; c = 0;
+    for (int r = 0; r < N; ++r) { v[r] = 0; for (int k = 0; k < N; ++k) v[r] += Jh[r][k] * s[k]; a += v[r] * v[r]; }
+    for (int i = 0; i < N; ++i) { a += s[i] * diag[i] * s[i]; b += gh[i] * s[i]; }
+    a *= 0.5;
+    if (s0) {
+        double uu = 0;
+        for (int r = 0; r < N; ++r) { double u = 0; for (int k = 0; k < N; ++k) u += Jh[r][k] * s0[k]; b += u * v[r]; uu += u * u; }
+        c = 0.5 * uu;
+        for (int i = 0; i < N; ++i) { c += gh[i] * s0[i]; b += s0[i] * diag[i] * s[i]; }
+        for (int i = 0; i < N; ++i) c += 0.5 * s0[i] * diag[i] * s0[i];
+    }
+}
+__device__ __forceinline__ double min_quad(double a, double b, double lo, double hi, double c, double& y) {
+    double t = lo; y = lo * (a * lo + b) + c;
+    double yh = hi * (a * hi + b) + c;
+    if (yh < y) { y = yh; t = hi; }
+    if (a != 0) { double e = -0.5 * b / a; if (lo < e && e < hi) { double ye = e * (a * e + b) + c; if (ye < y) { y = ye; t = e; } } }
+    return t;
+}
+// trf.py select_step :128-203
+template <int N> __device__ __forceinline__ double select_step(const double x[N], const double Jh[N][N], const double diag[N], const double gh[N],
+                                                              double p[N], double ph[N], const double d[N], double Delta, double lb, double theta,
+                                                              double step[N], double steph[N]) {
+    bool inb = true;
+    for (int i = 0; i < N; ++i) inb = inb && (x[i] + p[i] >= lb);
+    if (inb) { for (int i = 0; i < N; ++i) { step[i] = p[i]; steph[i] = ph[i]; } return -eval_quad<N>(Jh, gh, ph, diag); }
+    int hits[N];
+    double pstride = step_to_bound<N>(x, p, lb, hits);
+    double rh[N], r[N], xb[N];
+    for (int i = 0; i < N; ++i) { rh[i] = hits[i] != 0 ? -ph[i] : ph[i]; r[i] = d[i] * rh[i]; }
+    for (int i = 0; i < N; ++i) { p[i] *= pstride; ph[i] *= pstride; xb[i] = x[i] + p[i]; }
+    double to_tr;
+    {   // intersect_trust_region(p_h, r_h, Delta), common.py:17-54: positive root
+        double a = 0, b = 0, c = -Delta * Delta;
+        for (int i = 0; i < N; ++i) { a += rh[i] * rh[i]; b += ph[i] * rh[i]; c += ph[i] * ph[i]; }
+        double dd = sqrt(b * b - a * c);
+        double q = -(b + copysign(dd, b));
+        double t1 = q / a, t2 = c / q;
+        to_tr = fmax(t1, t2);
+    }
+    int h2[N];
+    double to_bound = step_to_bound<N>(xb, r, lb, h2);
+    double rs = fmin(to_bound, to_tr), rl, ru;
+    if (rs > 0) { rl = (1 - theta) * pstride / rs; ru = (rs == to_bound) ? theta * to_bound : to_tr; }
+    else { rl = 0; ru = -1; }
+    double rval = INFINITY;
+    if (rl <= ru) {
+        double a, b, c;
+        build_quad<N>(Jh, gh, rh, diag, ph, a, b, c);
+        double t = min_quad(a, b, rl, ru, c, rval);
+        for (int i = 0; i < N; ++i) { rh[i] = rh[i] * t + ph[i]; r[i] = rh[i] * d[i]; }
+    }
+    for (int i = 0; i < N; ++i) { p[i] *= theta; ph[i] *= theta; }
+    double pval = eval_quad<N>(Jh, gh, ph, diag);
+    double agh[N], ag[N];
+    for (int i = 0; i < N; ++i) { agh[i] = -gh[i]; ag[i] = d[i] * agh[i]; }
+    double to_tr2 = Delta / vnorm<N>(agh);
+    double to_b2 = step_to_bound<N>(x, ag, lb, h2);
+    double ags = to_b2 < to_tr2 ? theta * to_b2 : to_tr2;
+    double a, b, c, agval;
+    build_quad<N>(Jh, gh, agh, diag, nullptr, a, b, c);
+    ags = min_quad(a, b, 0.0, ags, 0.0, agval);
+    for (int i = 0; i < N; ++i) { agh[i] *= ags; ag[i] *= ags; }
+    if (pval < rval && pval < agval) { for (int i = 0; i < N; ++i) { step[i] = p[i]; steph[i] = ph[i]; } return -pval; }
+    if (rval < pval && rval < agval) { for (int i = 0; i < N; ++i) { step[i] = r[i]; steph[i] = rh[i]; } return -rval; }
+    for (int i = 0; i < N; ++i) { step[i] = ag[i]; steph[i] = agh[i]; }
+    return -agval;
+}
+
+// fun(x, f): N residuals of N unknowns.  x is updated in place.
+template <int N, class Fun> __device__ __forceinline__ void trf_bounded(Fun fun, double x[N], double lb) {
+    auto eval = [&](const double xx[N], double f[N], double J[N][N]) {
+        fun(xx, f);
+        for (int j = 0; j < N; ++j) {
+            double h = fd_step(xx[j]);
+            if (xx[j] + h < lb) h = -h;                       // _adjust_scheme_to_bounds, 1-sided
+            double x1[N], f1[N];
+            for (int i = 0; i < N; ++i) x1[i] = xx[i];
+            x1[j] = xx[j] + h;
+            double dx = x1[j] - xx[j];
+            fun(x1, f1);
+            for (int r = 0; r < N; ++r) J[r][j] = (f1[r] - f[r]) / dx;
+        }
+    };
+    for (int i = 0; i < N; ++i) {                              // make_strictly_feasible(x0), least_squares.py:828
+        double th = 1e-10 * fmax(1.0, fabs(lb));
+        if (x[i] - lb <= th) x[i] = lb + th;
+    }
+    double f[N], J[N][N], g[N];
+    eval(x, f, J);
+    int nfev = 1;
+    const int max_nfev = 100 * N;
+    double cost = 0;
+    for (int i = 0; i < N; ++i) cost += f[i] * f[i];
+    cost *= 0.5;
+    auto grad = [&]() { for (int c = 0; c < N; ++c) { g[c] = 0; for (int r = 0; r < N; ++r) g[c] += J[r][c] * f[r]; } };
+    grad();
+    double v[N], dv[N];
+    auto CL = [&]() { for (int i = 0; i < N; ++i) { if (g[i] > 0) { v[i] = x[i] - lb; dv[i] = 1.0; } else { v[i] = 1.0; dv[i] = 0.0; } } };
+    CL();
+    double Delta;
+    { double t[N]; for (int i = 0; i < N; ++i) t[i] = x[i] / sqrt(v[i]); Delta = vnorm<N>(t); if (Delta == 0) Delta = 1.0; }
+    double alpha = 0.0;
+    int term = 0;
+    for (;;) {
+        CL();
+        double g_norm = 0;
+        for (int i = 0; i < N; ++i) g_norm = fmax(g_norm, fabs(g[i] * v[i]));
+        if (g_norm < LSQ_GTOL) term = 1;
+        if (term != 0 || nfev >= max_nfev) break;
+        if (!(g_norm < INFINITY)) break;
+        double d[N], diag[N], gh[N], Jh[N][N], A[2 * N][N], fa[2 * N];
+        for (int i = 0; i < N; ++i) { d[i] = sqrt(v[i]); diag[i] = g[i] * dv[i]; gh[i] = d[i] * g[i]; }
+        for (int r = 0; r < N; ++r) { fa[r] = f[r]; fa[N + r] = 0.0; for (int c = 0; c < N; ++c) { Jh[r][c] = J[r][c] * d[c]; A[r][c] = Jh[r][c]; A[N + r][c] = (r == c) ? sqrt(diag[r]) : 0.0; } }
+        SvdN<N> sv = svd_aug(A, fa);
+        double theta = fmax(0.995, 1.0 - g_norm);
+        double actual = -1.0;
+        double xn[N], fn[N], Jn[N][N], cost_new = cost;
+        while (actual <= 0 && nfev < max_nfev) {
+            double ph[N], p[N], step[N], steph[N];
+            solve_tr_n<N>(sv, N, Delta, alpha, ph);
+            for (int i = 0; i < N; ++i) p[i] = d[i] * ph[i];
+            double predicted = select_step<N>(x, Jh, diag, gh, p, ph, d, Delta, lb, theta, step, steph);
+            for (int i = 0; i < N; ++i) { xn[i] = x[i] + step[i]; if (xn[i] <= lb) xn[i] = nextafter(lb, INFINITY); }   // make_strictly_feasible(rstep=0)
+            eval(xn, fn, Jn);
+            ++nfev;
+            double shn = vnorm<N>(steph);
+            bool fin = true;
+            for (int i = 0; i < N; ++i) fin = fin && isfinite(fn[i]);
+            if (!fin) { Delta = 0.25 * shn; continue; }
+            cost_new = 0;
+            for (int i = 0; i < N; ++i) cost_new += fn[i] * fn[i];
+            cost_new *= 0.5;
+            actual = cost - cost_new;
+            double ratio;
+            double Delta_new = update_radius(Delta, actual, predicted, shn, shn > 0.95 * Delta, ratio);
+            term = check_term(actual, cost, vnorm<N>(step), vnorm<N>(x), ratio);
+            if (term != 0) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual > 0) {
+            for (int i = 0; i < N; ++i) { x[i] = xn[i]; f[i] = fn[i]; for (int c = 0; c < N; ++c) J[i][c] = Jn[i][c]; }
+            cost = cost_new;
+            grad();
+        }
+    }
+}
+
+// ExpectedCoalTimeOnePop, CorrectLambda.py:67-72 (note the lam > 100 clamp)
+__device__ __forceinline__ double ect_one_pop(double lam, double T) {
+    double r = lam > 100.0 ? 0.0 : T / (exp(lam * T) - 1.0);
+    return 1.0 / lam - r;
+}
+// ExpectedCoalTimeOnePopNonConditional, CorrectLambda.py:79-80
+__device__ __forceinline__ double ect_noncond(double lam, double T) { return (1.0 - exp(-lam * T) * (1.0 + lam * T)) / lam; }
+
+// Residuals of the migrating two-population interval, evaluated for the base
+// point and both forward-difference points in one wave pass.
+// lane = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
+struct PairProblem {
+    double mu0, mu1;       // stretched to unit interval (CorrectLambda.py:293-298)
+    double lh0, lh1;       // stretched
+    double P[2][3];        // pair-state vectors at the start of the interval
+    bool cpfit;
+};
+struct PairEval {
+    double f[2];           // residual at the base point
+    double J[2][2];        // forward-difference Jacobian
+    double v[2][3];        // exp(M) P[k] at the base point
+    bool finite;
+};
+__device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, double x1, int lane, bool& guard) {
+    double h0 = fd_step(x0), h1 = fd_step(x1);
+    double xa = x0 + h0, xb = x1 + h1;
+    double dx0 = xa - x0, dx1 = xb - x1;            // recomputed as exactly representable (_numdiff.py)
+    int e = lane >> 1, k = lane & 1;
+    bool active = lane < 6;
+    double l0 = (e == 1) ? xa : x0;
+    double l1 = (e == 2) ? xb : x1;
+    double v[3];
+    double s = 0.0;
+    for (int i = 0; i < 3; ++i) { v[i] = k ? pb.P[1][i] : pb.P[0][i]; }
+    s = (v[0] + v[1]) + v[2];
+    double res;
+    if (pb.cpfit) {
+        // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
+        double w[3] = {v[0], v[1], v[2]};
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, guard);
+        double nch = exp(-(k ? pb.lh1 : pb.lh0)) * s;
+        res = ((w[0] + w[1]) + w[2]) - nch;
+        v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+    } else {
+        // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
+        double pn[3] = {v[0] / s, v[1] / s, v[2] / s};
+        double w[3] = {pn[0], pn[1], pn[2]};
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, guard);
+        double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
+        double d[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
+        double y[3], vec1[3], vec2[3];
+        solve3(M, d, y);
+        solve3(M, y, vec1);
+        double pnc = (w[0] + w[1]) + w[2];
+        solve3(M, w, vec2);                         // T = 1 after the stretch
+        double ect = (l0 * (vec2[0] - vec1[0]) + l1 * (vec2[1] - vec1[1])) / (1.0 - pnc);
+        double lam = k ? pb.lh1 : pb.lh0;           // ExpectedCoalTimeOnePopTmp :74-77 with T = 1
+        double pn1 = exp(-lam);
+        double tc1 = 1.0 / lam - 1.0 / (1.0 / pn1 - 1.0);
+        res = ect - tc1;
+        // the state vector handed on is exp(M) applied to the unnormalised vector
+        v[0] = w[0] * s; v[1] = w[1] * s; v[2] = w[2] * s;
+    }
+    PairEval o;
+    double fb0 = bcast(res, 0), fb1 = bcast(res, 1);
+    double fa0 = bcast(res, 2), fa1 = bcast(res, 3);
+    double fc0 = bcast(res, 4), fc1 = bcast(res, 5);
+    o.f[0] = fb0; o.f[1] = fb1;
+    o.J[0][0] = (fa0 - fb0) / dx0; o.J[1][0] = (fa1 - fb1) / dx0;
+    o.J[0][1] = (fc0 - fb0) / dx1; o.J[1][1] = (fc1 - fb1) / dx1;
+    for (int i = 0; i < 3; ++i) { o.v[0][i] = bcast(v[i], 0); o.v[1][i] = bcast(v[i], 1); }
+    o.finite = isfinite(fb0) && isfinite(fb1);
+    return o;
+}
+
+// trf_no_bounds (trf.py:401-560) on the residual above.  Returns x and the
+// propagated pair vectors exp(M(x)) P[k] (CorrectLambda.py:313-317).
+__device__ __forceinline__ void trf2_unbounded(const PairProblem& pb, double x[2], double vout[2][3], int lane, bool& guard) {
+    PairEval ev = pair_eval(pb, x[0], x[1], lane, guard);
+    double f[2] = {ev.f[0], ev.f[1]};
+    double J[2][2] = {{ev.J[0][0], ev.J[0][1]}, {ev.J[1][0], ev.J[1][1]}};
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) vout[k][i] = ev.v[k][i];
+    int nfev = 1;
+    const int max_nfev = 200;
+    double cost = 0.5 * (f[0] * f[0] + f[1] * f[1]);
+    double g[2] = {J[0][0] * f[0] + J[1][0] * f[1], J[0][1] * f[0] + J[1][1] * f[1]};
+    double Delta = sqrt(x[0] * x[0] + x[1] * x[1]);
+    if (Delta == 0) Delta = 1.0;
+    double alpha = 0.0;
+    int term = 0;
+    for (;;) {
+        double g_norm = fmax(fabs(g[0]), fabs(g[1]));
+        if (g_norm < LSQ_GTOL) term = 1;
+        if (term != 0 || nfev >= max_nfev) break;
+        if (!(g_norm < INFINITY)) break;                       // NaN residuals: give up (result fails downstream)
+        Svd2 sv = svd_mx2<2>(J, f);
+        double actual = -1.0;
+        double xn[2] = {x[0], x[1]}, fn[2] = {f[0], f[1]}, cost_new = cost;
+        PairEval en = ev;
+        while (actual <= 0 && nfev < max_nfev) {
+            double p[2];
+            solve_tr(sv, 2, Delta, alpha, p);
+            double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
+            double predicted = -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
+            xn[0] = x[0] + p[0]; xn[1] = x[1] + p[1];
+            en = pair_eval(pb, xn[0], xn[1], lane, guard);
+            ++nfev;
+            double step_norm = sqrt(p[0] * p[0] + p[1] * p[1]);
+            if (!en.finite) { Delta = 0.25 * step_norm; continue; }
+            fn[0] = en.f[0]; fn[1] = en.f[1];
+            cost_new = 0.5 * (fn[0] * fn[0] + fn[1] * fn[1]);
+            actual = cost - cost_new;
+            double ratio;
+            double Delta_new = update_radius(Delta, actual, predicted, step_norm, step_norm > 0.95 * Delta, ratio);
+            term = check_term(actual, cost, step_norm, sqrt(x[0] * x[0] + x[1] * x[1]), ratio);
+            if (term != 0) break;
+            alpha *= Delta / Delta_new;
+            Delta = Delta_new;
+        }
+        if (actual > 0) {
+            x[0] = xn[0]; x[1] = xn[1]; f[0] = fn[0]; f[1] = fn[1]; cost = cost_new;
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = en.J[r][c];
+            for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) vout[k][i] = en.v[k][i];
+            g[0] = J[0][0] * f[0] + J[1][0] * f[1];
+            g[1] = J[0][1] * f[0] + J[1][1] * f[1];
+        }
+    }
+}
+
+// ------------------------------------------------ two-population correction --
+// MigrationInference.CorrectLambdas, loop t < splitT (:311-354).  All values are
+// wave-uniform except inside pair_eval.  Returns false on "correction failed".
+struct PairState { double p[2][3]; };
+
+__device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu1) {
+    double r = pu0 + pu1;                                        // :315-323
+    if (!(r > 0)) return;
+    int a = pu0 > 0 ? 0 : 1, b = 1 - a;
+    for (int k = 0; k < 2; ++k) {
+        double pa = ps.p[k][a], pb = ps.p[k][b], pc = ps.p[k][2];
+        double omr = 1.0 - r;
+        ps.p[k][a] = pa * (omr * omr);
+        ps.p[k][b] = pa * (r * r) + pb + pc * r;
+        ps.p[k][2] = pa * 2 * omr * r + pc * omr;
+    }
+}
+
+// One interval of SolveLambdaSystem (CorrectLambda.py:266-317); lc < 0 signals failure.
+__device__ __forceinline__ void correct_interval(const DevModel& m, double lh0, double lh1, double T, double mu0, double mu1,
+                                                 PairState& ps, double lc[2], int lane, bool& guard) {
+    const bool cpfit = m.flags & MISTI_CPFIT;
+    double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
+    double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
+    double mix = 0.0;
+    for (int i = 0; i < 3; ++i) { double d = ps.p[0][i] / s0 - ps.p[1][i] / s1; mix += d * d; }
+    mix = sqrt(mix);
+    if (mix < m.mixture_th) { lc[0] = lc[1] = -1.0; return; }                       // :271-272
+    if (mu0 + mu1 < 1e-10) {
+        if (cpfit) {
+            // SolveNoMigration1 :213-235
+            double A1 = ps.p[0][0] / s0, A2 = ps.p[0][1] / s0, A3 = ps.p[1][0] / s1, A4 = ps.p[1][1] / s1;
+            double C1 = ps.p[0][2] / s0, C2 = ps.p[1][2] / s1;
+            double D = A1 * A4 - A2 * A3;
+            double B1 = A4 / D, B2 = -A2 / D, B3 = -A3 / D, B4 = A1 / D;
+            double X1 = exp(-lh0 * T) - C1, X2 = exp(-lh1 * T) - C2;
+            double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
+            if (y0 > 0 && y1 > 0) { lc[0] = -log(y0) / T; lc[1] = -log(y1) / T; }
+            else { lc[0] = lc[1] = -1.0; }
+            double e0 = exp(-lc[0] * T), e1 = exp(-lc[1] * T);
+            for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
+            return;
+        }
+        // SolveNoMigration :253-264: bounded 2-D fit of the conditional expected coalescence time
+        double pr[2][3];
+        for (int i = 0; i < 3; ++i) { pr[0][i] = ps.p[0][i] / s0; pr[1][i] = ps.p[1][i] / s1; }
+        double tgt0 = ect_one_pop(lh0, T), tgt1 = ect_one_pop(lh1, T);
+        auto resid = [&](const double l[2], double f[2]) {          // LambdaSystemNoMigration :237-251
+            double e0 = exp(-l[0] * T), e1 = exp(-l[1] * T);
+            double n0 = ect_noncond(l[0], T), n1 = ect_noncond(l[1], T);
+            for (int k = 0; k < 2; ++k) {
+                double pnc = pr[k][0] * e0 + pr[k][1] * e1 + pr[k][2];
+                double ct = (pr[k][0] * n0 + pr[k][1] * n1) / (1.0 - pnc);
+                f[k] = ct - (k ? tgt1 : tgt0);
+            }
+        };
+        double x[2] = {lh0, lh1};
+        trf_bounded<2>(resid, x, 0.01 * fmin(lh0, lh1));
+        lc[0] = x[0]; lc[1] = x[1];
+        double e0 = exp(-lc[0] * T), e1 = exp(-lc[1] * T);
+        for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
+        return;
+    }
+    double n0 = 0, n1 = 0, nd = 0;                                                   // :278-290
+    for (int i = 0; i < 3; ++i) { n0 += ps.p[0][i] * ps.p[0][i]; n1 += ps.p[1][i] * ps.p[1][i]; double d = ps.p[0][i] - ps.p[1][i]; nd += d * d; }
+    n0 = sqrt(n0); n1 = sqrt(n1); nd = sqrt(nd);
+    if (nd < 0.02 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; }
+    PairProblem pb;
+    pb.mu0 = mu0 * T; pb.mu1 = mu1 * T; pb.lh0 = lh0 * T; pb.lh1 = lh1 * T;         // stretch :293-298
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
+    pb.cpfit = cpfit;
+    double x[2] = {pb.lh0, pb.lh1};
+    double v[2][3];
+    trf2_unbounded(pb, x, v, lane, guard);
+    lc[0] = x[0] / T; lc[1] = x[1] / T;                                              // :312
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) ps.p[k][i] = v[k][i];
+}
+
+// ----------------------------------------------------------- the kernels ----
+// Candidate structure shared by both kernels: fractional split (:89-99), negative
+// parameter guard (:569-572), split beyond the grid.
+__device__ __forceinline__ int setup_candidate(const DevModel& m, double st, const double* par, Grid& G) {
+    int status = MISTI_OK;
+    G.times = m.times; G.lh = m.lh; G.numT0 = m.numT;
+    double fl = floor(st);
+    G.frac = st - fl;
+    int s = (int)fl;
+    G.ins = -1; G.split = s; G.numT = m.numT;
+    if (!(st >= 0) || !(st >= (double)m.sample_date) || s > m.numT) status = MISTI_BAD_STRUCTURE;
+    else if (G.frac != 0.0) {
+        if (s > m.numT - 2) status = MISTI_BAD_STRUCTURE;
+        else { G.ins = s; G.split = s + 1; G.numT = m.numT + 1; }
+    }
+    for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
+    if (status == MISTI_OK && G.split >= G.numT) status = MISTI_INF_COAL;
+    return status;
+}
+
+// Kernel 1: lambda correction (CorrectLambdas + Smooth, MigrationInference.py:305-405).
+// One wave per candidate; writes the corrected rates lc[cand][numT+1][2], the
+// pair-state trace and the status.  LDS per wave (doubles): lc[2*(numT0+1)].
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
+                    double* __restrict__ lc_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
+    extern __shared__ double lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (cand >= n_cand) return;
+    const int lc_rows = m.numT + 1;
+    double* lcb = lds + (size_t)wave * (2 * lc_rows);
+
+    const double* par = params ? params + cand * m.n_param : nullptr;
+    Grid G;
+    int status = setup_candidate(m, split_time[cand], par, G);
+    Model mod{&m, par, G.split};
+    for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = 0.0;
+    lds_fence();
+
+    const bool correct = !(m.flags & MISTI_TRUE_EPS);
+    const bool cpfit = m.flags & MISTI_CPFIT;
+    double* pr_c = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
+
+    // ---- lambda correction, two-population part (:307-354) -------------------
+    bool guard = false;     // an absurd solver iterate was cut off (results would differ from the reference)
+    PairState ps;
+    ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
+    ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
+    if (status == MISTI_OK) {
+        if (pr_c && lane == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
+        for (int t = 0; t < G.split; ++t) {
+            double pu0, pu1, mu0, mu1;
+            mod.pulse(t, pu0, pu1);
+            mod.mig(t, mu0, mu1);
+            pulse_pairs(ps, pu0, pu1);
+            double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
+            double lc[2] = {lh0, lh1};
+            if (correct) {
+                correct_interval(m, lh0, lh1, G.T(t), mu0, mu1, ps, lc, lane, guard);
+                if (!(lc[0] > 0) || !(lc[1] > 0)) {                                    // :346-348 (NaN fails too)
+                    status = (isnan(lc[0]) || isnan(lc[1])) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
+                    break;
+                }
+            }
+            if (lane == 0) { lcb[2 * t] = lc[0]; lcb[2 * t + 1] = lc[1]; }
+            if (pr_c && lane == 0) {
+                double* r = pr_c + 6 * (t + 1);
+                r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
+            }
+        }
+    }
+    if (status == MISTI_OK) {
+        lds_fence();
+        // ---- post-split rates (:353-376); nc is a probability used as a log ----
+        double nc0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
+        double nc1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
+        double delta = nc1 - nc0;
+        double ed = exp(delta);
+        const int last = G.numT - 1;
+        for (int base = G.split; base < G.numT; base += 64) {
+            int t = base + lane;
+            if (t < last) {
+                double T = G.T(t);
+                double lam = 1.0;
+                if (T != 0) {
+                    double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
+                    if (cpfit) {
+                        double pnc = (exp(-T * lh0) + exp(delta - T * lh1)) / (1.0 + ed);   // :366
+                        lam = -log(pnc) / T;
+                    } else {
+                        // FitSinglePop :88-92 with P0 = [[exp(nc0),0,0],[exp(nc1),0,0]] (:361)
+                        double pa = exp(nc0), pb = exp(nc1);
+                        double w0 = pa / (pa + pb), w1 = pb / (pa + pb);
+                        double Te = w0 * ect_one_pop(lh0, T) + w1 * ect_one_pop(lh1, T);
+                        double x[1] = {w0 * lh0 + w1 * lh1};
+                        auto resid = [&](const double l[1], double f[1]) { f[0] = ect_one_pop(l[0], T) - Te; };
+                        trf_bounded<1>(resid, x, 0.01 * fmin(lh0, lh1));
+                        lam = x[0];
+                    }
+                }
+                lcb[2 * t] = lam; lcb[2 * t + 1] = lam;
+            } else if (t == last) {
+                double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
+                double lam = (1.0 + ed) / (1.0 / lh0 + ed / lh1);                            // :372-376
+                lcb[2 * t] = lam; lcb[2 * t + 1] = lam;
+            }
+        }
+        lds_fence();
+        // ---- Smooth (:380-405): time-weighted mean of lc over runs of constant lh, t < split
+        if (m.flags & MISTI_SMOOTH) {
+            double sm[SMOOTH_REPS][2];   // intervals rep*64+lane, both genomes
+#pragma unroll
+            for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
+                int t = rep * 64 + lane;
+                for (int k = 0; k < 2; ++k) {
+                    double v = 0.0;
+                    if (t < G.split) {
+                        int a = m.run_start[k * m.numT + t];
+                        int b = m.run_end[k * m.numT + t];
+                        if (b > G.split) b = G.split;
+                        double acc = 0.0, tt = 0.0;
+                        for (int j = a; j < b; ++j) { double Tj = G.T(j); acc += lcb[2 * j + k] * Tj; tt += Tj; }
+                        v = acc / tt;
+                    }
+                    sm[rep][k] = v;
+                }
+            }
+            lds_fence();
+#pragma unroll
+            for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
+                int t = rep * 64 + lane;
+                if (t < G.split) { lcb[2 * t] = sm[rep][0]; lcb[2 * t + 1] = sm[rep][1]; }
+            }
+            lds_fence();
+        }
+        for (int i = lane; i < 2 * G.numT; i += 64) { double v = lcb[i]; if (!(v == v)) status = MISTI_NUMERIC; }
+        status = (guard || __any(status != MISTI_OK)) ? MISTI_NUMERIC : MISTI_OK;
+    }
+
+    // ---- outputs ------------------------------------------------------------
+    if (lane == 0) status_out[cand] = status;
+    lds_fence();
+    double* o = lc_out + cand * (int64_t)lc_rows * 2;
+    for (int i = lane; i < 2 * lc_rows; i += 64) o[i] = (i < 2 * G.numT) ? lcb[i] : 0.0;   // partial (up to the failing interval) when status != OK
+}
+
+// Kernel 2: expected joint spectrum (JAFSpectrum, MigrationInference.py:467-540).
+// One wave per candidate, lane = state of the 44-state chain.
+// LDS per wave (doubles): xbuf[64] | lc[2*(numT0+1)]
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
+                     const double* __restrict__ lc_in, double* __restrict__ jafs_out, int32_t* __restrict__ status_io) {
+    extern __shared__ double lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (cand >= n_cand) return;
+    const int lc_rows = m.numT + 1;
+    double* xbuf = lds + (size_t)wave * (64 + 2 * lc_rows);
+    double* lcb = xbuf + 64;
+    int status = status_io[cand];
+    if (status != MISTI_OK) {
+        if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
+        return;
+    }
+    const double* par = params ? params + cand * m.n_param : nullptr;
+    Grid G;
+    (void)setup_candidate(m, split_time[cand], par, G);
+    Model mod{&m, par, G.split};
+    {
+        const double* src = lc_in + cand * (int64_t)lc_rows * 2;
+        for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = src[i];
+    }
+    lds_fence();
+    double jafs[7] = {0, 0, 0, 0, 0, 0, 0};
+
+    if (status == MISTI_OK) {
+        // ---- expected spectrum, two-population part (:467-506) ----------------
+        int srcl[MAXNZ], knd[MAXNZ]; double mlt[MAXNZ];
+        for (int n = 0; n < MAXNZ; ++n) { srcl[n] = c_tab.src[n][lane]; knd[n] = c_tab.kind[n][lane]; mlt[n] = (double)c_tab.mult[n][lane]; }
+        double dc0 = c_tab.dcnt[0][lane], dc1 = c_tab.dcnt[1][lane], dc2 = c_tab.dcnt[2][lane], dc3 = c_tab.dcnt[3][lane];
+        const bool live = lane < NS2;
+        double x = (lane == 2) ? 1.0 : 0.0;
+        double w_pre = 0.0, w_post = 0.0;          // occupation integrals before / from the sample date
+        for (int t = 0; t <= G.split && t < G.numT; ++t) {
+            if (t == m.sample_date) {
+                // AncientSampleP0 (TwoPopulations.py:246-262)
+                xbuf[lane] = x; lds_fence();
+                double nx = 0.0;
+                for (int a = 0; a < 2; ++a) if (lane == c_tab.anc_dst[a]) for (int j = 0; j < c_tab.anc_n[a]; ++j) nx += xbuf[c_tab.anc_src[a][j]];
+                lds_fence();
+                x = nx;
+            }
+            if (t == G.split) break;
+            double pu0, pu1, mu0, mu1;
+            mod.pulse(t, pu0, pu1);
+            mod.mig(t, mu0, mu1);
+            double pr = pu0 + pu1;
+            if (pr > 0) {
+                // PulseMigration (TwoPopulations.py:361-377)
+                int from = pu0 > 0 ? 0 : 1;
+                xbuf[lane] = x; lds_fence();
+                double pw_s[5], pw_m[5];
+                pw_s[0] = pw_m[0] = 1.0;
+                for (int i = 1; i < 5; ++i) { pw_s[i] = pw_s[i - 1] * (1.0 - pr); pw_m[i] = pw_m[i - 1] * pr; }
+                double nx = 0.0;
+                int n = live ? c_tab.pulse_n[from][lane] : 0;
+                for (int j = 0; j < n; ++j) {
+                    int ab = c_tab.pulse_ab[from][lane][j];
+                    int mul = ab >> 8, a = (ab >> 4) & 15, b = ab & 15;
+                    nx += xbuf[c_tab.pulse_src[from][lane][j]] * ((double)mul * pw_s[a] * pw_m[b]);
+                }
+                lds_fence();
+                x = nx;
+            }
+            double la0 = lcb[2 * t], la1 = lcb[2 * t + 1];
+            double T = G.T(t);
+            // largest total exit rate over the 44 states (4 lineages dominate)
+            double r40 = 6 * la0 + 4 * mu0, r04 = 6 * la1 + 4 * mu1;
+            double r31 = 3 * la0 + 3 * mu0 + mu1, r13 = 3 * la1 + 3 * mu1 + mu0;
+            double r22 = la0 + la1 + 2 * mu0 + 2 * mu1;
+            double q = T * fmax(fmax(r40, r04), fmax(fmax(r31, r13), r22));
+            if (!(q < 1e300)) { status = MISTI_NUMERIC; break; }
+            int nsub = 1;
+            if (q > Q_SUB) { double nn = ceil(q / Q_SUB); if (nn > (double)MAX_SUB) { status = MISTI_STIFF; break; } nsub = (int)nn; }
+            double sc = 1.0 / (double)nsub;
+            double Ts = T * sc, qs = q * sc;
+            double rate[4] = {la0, la1, mu0, mu1};
+            double cf[MAXNZ];
+            for (int n = 0; n < MAXNZ; ++n) cf[n] = mlt[n] * rate[knd[n]] * Ts;
+            double dg = qs - (dc0 * la0 + dc1 * la1 + dc2 * mu0 + dc3 * mu1) * Ts;
+            double eq = exp(-qs);
+            double wint = 0.0;
+            for (int sub = 0; sub < nsub; ++sub) {
+                double p = eq * x, ii = 0.0;
+                double accp = p, acci = 0.0;
+                double b = eq, bprev = 1.0;
+                for (int k = 1; k < 1000; ++k) {
+                    double inv = 1.0 / (double)k;
+                    xbuf[lane] = p;
+                    lds_fence();
+                    double r0 = xbuf[srcl[0]], r1 = xbuf[srcl[1]], r2 = xbuf[srcl[2]], r3 = xbuf[srcl[3]];
+                    lds_fence();
+                    double pn = (dg * p + ((cf[0] * r0 + cf[1] * r1) + (cf[2] * r2 + cf[3] * r3))) * inv;
+                    ii = (Ts * p + qs * ii) * inv;
+                    p = pn;
+                    accp += p; acci += ii;
+                    bprev = b;
+                    b *= qs * inv;
+                    if (bprev < 1e-19 && (double)k > qs) break;
+                }
+                x = accp; wint += acci;
+            }
+            if (t < m.sample_date) w_pre += wint; else w_post += wint;
+        }
+        if (status == MISTI_OK) {
+            // two-population share of the spectrum: lanes 0..6 each sum one class
+            xbuf[lane] = live ? w_post : 0.0; lds_fence();
+            double jp = 0.0;
+            if (lane < 7) for (int i = 0; i < NS2; ++i) jp += (double)c_tab.jaf[lane][i] * xbuf[i];
+            lds_fence();
+            xbuf[lane] = live ? w_pre : 0.0; lds_fence();
+            if (lane < 2) for (int i = 0; i < NS2; ++i) jp += (double)c_tab.jaf[lane][i] * xbuf[i];
+            lds_fence();
+            // CollapsePops (:518-528)
+            xbuf[lane] = live ? x : 0.0; lds_fence();
+            double c8 = 0.0;
+            if (lane < NS1) for (int i = c_tab.grp_lo[lane]; i < c_tab.grp_hi[lane]; ++i) c8 += xbuf[i];
+            lds_fence();
+            double P8[NS1];
+            for (int i = 0; i < NS1; ++i) P8[i] = bcast(c8, i);
+            // ---- one-population part: Kingman coalescent in rescaled time --------
+            // P(s) = V1 e^-s + V3 e^-3s + V6 e^-6s, s = int lc dt; occupation integral of
+            // interval t is (1/lc_t) * int_{S_t}^{S_t+tau_t} P(s) ds (OnePopulation.py:153-178,
+            // SolveDifEq :530-540 incl. the last, infinite interval).
+            double x0 = P8[0];
+            const double a3[3] = {1.0, 4.0, 1.0};
+            double X[3], V1[NS1], V3[NS1], V6[NS1];
+            for (int i = 0; i < 3; ++i) X[i] = P8[1 + i] + a3[i] * x0 / 3.0;
+            // b[j][i]: 3-lineage state i -> 2-lineage state 4+j (one-population generator / la)
+            const double bm[4][3] = {{2, 1, 0}, {0, 1, 2}, {1, 0, 1}, {0, 1, 0}};
+            V6[0] = x0; V3[0] = 0; V1[0] = 0;
+            for (int i = 0; i < 3; ++i) { V6[1 + i] = -a3[i] * x0 / 3.0; V3[1 + i] = X[i]; V1[1 + i] = 0; }
+            for (int j = 0; j < 4; ++j) {
+                double sx = 0, sa = 0;
+                for (int i = 0; i < 3; ++i) { sx += bm[j][i] * X[i]; sa += bm[j][i] * a3[i]; }
+                V6[4 + j] = sa * x0 / 15.0;
+                V3[4 + j] = -sx / 2.0;
+                V1[4 + j] = P8[4 + j] + sx / 2.0 - sa * x0 / 15.0;
+            }
+            double G1 = 0, G3 = 0, G6 = 0;           // sum_t e^{-a S_t} (1 - e^{-a tau_t}) / (a lc_t)
+            double carry = 0.0;
+            const int last = G.numT - 1;
+            for (int base = G.split; base < G.numT; base += 64) {
+                int t = base + lane;
+                double lam = 1.0, tau = 0.0;
+                if (t < last) { lam = lcb[2 * t]; tau = lam * G.T(t); }
+                else if (t == last) { lam = lcb[2 * t]; }
+                double inc = tau;                      // inclusive prefix sum over the wave
+                for (int o = 1; o < 64; o <<= 1) { double u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+                double S = carry + (inc - tau);
+                if (t < last) {
+                    G1 += exp(-S) * (-expm1(-tau)) / lam;
+                    G3 += exp(-3 * S) * (-expm1(-3 * tau)) / (3 * lam);
+                    G6 += exp(-6 * S) * (-expm1(-6 * tau)) / (6 * lam);
+                } else if (t == last) {
+                    G1 += exp(-S) / lam; G3 += exp(-3 * S) / (3 * lam); G6 += exp(-6 * S) / (6 * lam);
+                }
+                carry += bcast(inc, 63);
+            }
+            for (int o = 32; o > 0; o >>= 1) { G1 += __shfl_xor(G1, o, 64); G3 += __shfl_xor(G3, o, 64); G6 += __shfl_xor(G6, o, 64); }
+            // assemble: lane c < 7 holds class c
+            double j1 = 0.0;
+            if (lane < 7) for (int i = 0; i < NS1; ++i) j1 += (double)c_tab.jaf1[lane][i] * (V1[i] * G1 + V3[i] * G3 + V6[i] * G6);
+            double jc = jp + j1;
+            double tot = 0.0;
+            for (int c = 0; c < 7; ++c) { jafs[c] = bcast(jc, c); tot += jafs[c]; }   // :583-584
+            for (int c = 0; c < 7; ++c) jafs[c] /= tot;
+            for (int c = 0; c < 7; ++c) if (!(jafs[c] == jafs[c])) status = MISTI_NUMERIC;
+        }
+    }
+    // ---- outputs ------------------------------------------------------------
+    if (lane == 0 && status != MISTI_OK) status_io[cand] = status;
+    if (lane < 7) {
+        double v = NAN;
+        for (int c = 0; c < 7; ++c) if (lane == c) v = jafs[c];
+        jafs_out[cand * 7 + lane] = (status == MISTI_OK) ? v : NAN;
+    }
+}
+
+// ------------------------------------------------------- replicate epilogue --
+// llh_const of SetJAFS (MigrationInference.py:217-227): one thread per replicate.
+__global__ void llh_const_kernel(int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rep) return;
+    const double* d = jsfs + r * 8 + 1;
+    double snps = 0.0;
+    for (int i = 0; i < 7; ++i) snps += d[i];
+    double c = lgamma(snps + 1.0);
+    if (unfolded) { for (int i = 0; i < 7; ++i) c -= lgamma(d[i] + 1.0); }
+    else {
+        c -= lgamma(d[0] + d[6] + 1.0);
+        c -= lgamma(d[1] + d[5] + 1.0);
+        c -= lgamma(d[2] + d[4] + 1.0);
+        c -= lgamma(d[3] + 1.0);
+    }
+    consts[r] = c;
+}
+
+// llk[c][r] = const[r] + sum_i data[r][i] log JAFS[c][i]  (folded: pairs 0+6, 1+5, 2+4, 3)
+// MigrationInference.py:600-609.  One block = one candidate x LLK_TILE replicates;
+// writes are 8 B per lane, coalesced along r.
+__global__ __launch_bounds__(256)
+void llk_kernel(int64_t n_cand, const double* __restrict__ jafs, const int32_t* __restrict__ status,
+                int64_t n_rep, const double* __restrict__ jsfs, const double* __restrict__ consts,
+                double* __restrict__ llk, int unfolded) {
+    __shared__ double lj[7];
+    const int64_t c = blockIdx.y;
+    const int st = status ? status[c] : MISTI_OK;
+    if (threadIdx.x < 7) {
+        const double* J = jafs + c * 7;
+        double v;
+        if (unfolded) v = log(J[threadIdx.x]);
+        else {
+            int i = threadIdx.x;
+            v = (i < 3) ? log(J[i] + J[6 - i]) : (i == 3 ? log(J[3]) : 0.0);
+        }
+        lj[threadIdx.x] = v;
+    }
+    __syncthreads();
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (int64_t)gridDim.x * blockDim.x) {
+        double out;
+        if (st != MISTI_OK) out = -INFINITY;
+        else {
+            const double* d = jsfs + r * 8 + 1;
+            double a = consts[r];
+            if (unfolded) { for (int i = 0; i < 7; ++i) a += d[i] * lj[i]; }
+            else {
+                a += (d[0] + d[6]) * lj[0];
+                a += (d[1] + d[5]) * lj[1];
+                a += (d[2] + d[4]) * lj[2];
+                a += d[3] * lj[3];
+            }
+            out = a;
+        }
+        llk[c * n_rep + r] = out;
+    }
+}
+
+// ----------------------------------------------------------- launchers -------
+hipError_t upload_tables(const DevTables& t) { return hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(DevTables)); }
+
+size_t correct_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (2 * (numT + 1)) * sizeof(double); }
+size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (64 + 2 * (numT + 1)) * sizeof(double); }
+
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+                          double* lc, double* pr, int32_t* status, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    hipLaunchKernelGGL(correct_kernel, grid, dim3(WAVES_PER_BLOCK * 64), correct_lds_bytes(m.numT), stream,
+                       m, n_cand, split, params, lc, pr, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+                           const double* lc, double* jafs, int32_t* status, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
+    hipLaunchKernelGGL(spectrum_kernel, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
+                       m, n_cand, split, params, lc, jafs, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream) {
+    if (n_rep <= 0) return hipSuccess;
+    hipLaunchKernelGGL(llh_const_kernel, dim3((unsigned)((n_rep + 255) / 256)), dim3(256), 0, stream, n_rep, jsfs, consts, unfolded);
+    return hipGetLastError();
+}
+
+hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
+                      const double* consts, double* llk, int unfolded, hipStream_t stream) {
+    if (n_cand <= 0 || n_rep <= 0) return hipSuccess;
+    unsigned bx = (unsigned)((n_rep + 255) / 256);
+    if (bx > 64) bx = 64;
+    for (int64_t c0 = 0; c0 < n_cand; c0 += 65535) {
+        int64_t nc = n_cand - c0 < 65535 ? n_cand - c0 : 65535;
+        hipLaunchKernelGGL(llk_kernel, dim3(bx, (unsigned)nc), dim3(256), 0, stream,
+                           nc, jafs + c0 * 7, status ? status + c0 : nullptr, n_rep, jsfs, consts, llk + c0 * n_rep, unfolded);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace misti

@@ -1,0 +1,406 @@
+"""Python host of the HIP likelihood engine.
+
+Two layers:
+
+``Engine``
+    thin, batch-shaped wrapper of the C ABI (``include/misti_hip.h``): one
+    model (merged PSMC grid, band/pulse structure, flags) on one GPU, evaluated
+    for a batch of candidates x bootstrap JSFS replicates.
+
+``MigrationInference``
+    mirror of the reference class of the same name
+    (``/root/reference/MigrationInference.py:35-739``): same constructor
+    signature, keyword flags, attributes (``.JAFS .lc .lh .mi .pu .Pr .llh
+    .times .numT .splitT .dataJAFS .llh_const``), ``JAFSLikelihood(mu)``,
+    ``Solve(tol)``, counters and messages - so callers such as ``MiSTI.py`` and
+    ``migrationIO.OutputMigration`` work unchanged on top of the GPU path.
+
+There is no CPU path here: if ``libmisti_hip.so`` cannot be loaded or no HIP
+device is present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import CPFIT, SMOOTH, TRUE_EPS, UNFOLDED, MistiError, STATUS_TEXT
+
+__all__ = ["Engine", "MigrationInference", "ModelError", "BatchResult"]
+
+
+class ModelError(SystemExit):
+    """Raised where the reference prints an error and calls ``sys.exit(0)``
+    (``PrintError``, MigrationInference.py:300-303).  Uncaught, the process exits
+    with status 0 exactly as the reference does; a caller may also catch it."""
+
+    def __init__(self, func, text):
+        self.message = "MigrationInference class error in function %s(): %s" % (func, text)
+        print(self.message)
+        super().__init__(0)
+
+
+class BatchResult:
+    """Outputs of one batch: ``llk[C][R]``, ``jafs[C][7]``, ``status[C]`` and, if
+    requested, ``lc[C][numT+1][2]`` and ``pr[C][numT+2][6]``."""
+    __slots__ = ("llk", "jafs", "status", "lc", "pr")
+
+    def __init__(self, llk, jafs, status, lc=None, pr=None):
+        self.llk, self.jafs, self.status, self.lc, self.pr = llk, jafs, status, lc, pr
+
+    @property
+    def fraction_failed(self):
+        return float((self.status != 0).mean()) if self.status.size else 0.0
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Engine:
+    """One model on one GPU (``misti_create`` ... ``misti_destroy``).
+
+    Parameters
+    ----------
+    times : [numT-1] interval lengths;  lh : [numT][2] PSMC rates.
+    bands : iterable of ``(pop, start, end, value, param)`` with pop in {0,1},
+        ``end == -1`` meaning "the candidate's split index" and ``param`` the index
+        into the candidate parameter vector or -1 for a fixed rate.
+    pulses : iterable of ``(pop, time, value, param)``.
+    """
+
+    def __init__(self, times, lh, bands=(), pulses=(), n_param=0, cpfit=False, true_eps=False, smooth=False,
+                 unfolded=False, sample_date=0, mixture_th=0.0, device=0):
+        self._ctx = C.c_void_p()
+        self._lib = _lib.load()
+        times = _f64(times)
+        lh = _f64(lh)
+        self.numT = int(lh.shape[0])
+        if lh.ndim != 2 or lh.shape[1] != 2 or times.shape != (self.numT - 1,):
+            raise ValueError("times must have numT-1 entries and lh shape [numT][2]")
+        self.n_param = int(n_param)
+        self.flags = (CPFIT if cpfit else 0) | (TRUE_EPS if true_eps else 0) | (SMOOTH if smooth else 0) | (UNFOLDED if unfolded else 0)
+        self.unfolded = bool(unfolded)
+        bands = list(bands)
+        pulses = list(pulses)
+        b_arr = (_lib.Band * max(1, len(bands)))()
+        for i, (pop, start, end, value, param) in enumerate(bands):
+            b_arr[i] = _lib.Band(int(pop), int(start), int(end), int(param), float(value))
+        p_arr = (_lib.Pulse * max(1, len(pulses)))()
+        for i, (pop, time, value, param) in enumerate(pulses):
+            p_arr[i] = _lib.Pulse(int(pop), int(time), int(param), 0, float(value))
+        m = _lib.Model(self.numT, int(sample_date), self.flags, len(bands), len(pulses), self.n_param, float(mixture_th),
+                       times.ctypes.data_as(C.POINTER(C.c_double)), lh.ctypes.data_as(C.POINTER(C.c_double)),
+                       b_arr, p_arr)
+        ctx = C.c_void_p()
+        _lib.check(self._lib.misti_create(C.byref(m), int(device), C.byref(ctx)))
+        self._ctx = ctx
+        self.device = int(device)
+
+    # -- lifetime --------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.misti_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host-buffer evaluation ----------------------------------------------
+    def evaluate(self, split_time, params=None, jsfs=None, want_lc=False, want_pr=False):
+        """``misti_eval_batch``: NumPy in, NumPy out (copies over PCIe)."""
+        split = _f64(np.atleast_1d(split_time))
+        n = split.shape[0]
+        P = self.n_param
+        par = None
+        if P:
+            par = _f64(params, (n, P))
+        rows = _f64(jsfs, (-1, 8)) if jsfs is not None and len(jsfs) else np.zeros((0, 8))
+        R = rows.shape[0]
+        llk = np.empty((n, R))
+        jafs = np.empty((n, 7))
+        status = np.empty(n, dtype=np.int32)
+        lc = np.empty((n, self.numT + 1, 2)) if want_lc else None
+        pr = np.empty((n, self.numT + 2, 6)) if want_pr else None
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+        _lib.check(self._lib.misti_eval_batch(self._ctx, n, ptr(split), ptr(par), R, ptr(rows), ptr(llk), ptr(jafs),
+                                              ptr(lc), ptr(pr), ptr(status)))
+        return BatchResult(llk, jafs, status, lc, pr)
+
+    # -- device-buffer evaluation (torch tensors on this device) ------------------
+    def use_stream(self, stream_handle):
+        """Issue kernels on an existing hipStream_t (int handle), e.g.
+        ``torch.cuda.current_stream().cuda_stream``; ``None`` restores the own stream."""
+        _lib.check(self._lib.misti_set_stream(self._ctx, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def evaluate_dev(self, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0):
+        """``misti_eval_batch_dev``: raw device addresses (ints); asynchronous."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _lib.check(self._lib.misti_eval_batch_dev(self._ctx, int(n_cand), v(d_split), v(d_params), int(n_rep), v(d_jsfs),
+                                                  v(d_llk), v(d_jafs), v(d_lc), v(d_pr), v(d_status)))
+
+    def llk_dev(self, n_cand, d_jafs, d_status, n_rep, d_jsfs, d_llk):
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _lib.check(self._lib.misti_llk_dev(self._ctx, int(n_cand), v(d_jafs), v(d_status), int(n_rep), v(d_jsfs), v(d_llk)))
+
+    def sync(self):
+        _lib.check(self._lib.misti_sync(self._ctx))
+
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.misti_enable_timing(self._ctx, 1 if on else 0))
+
+    def kernel_times(self, reset=False):
+        """(ms per kernel, launches per kernel) accumulated from HIP events around every launch."""
+        ms = (C.c_double * 3)()
+        n = (C.c_int64 * 3)()
+        _lib.check(self._lib.misti_kernel_times(self._ctx, ms, n, 1 if reset else 0))
+        names = ("correct", "spectrum", "llk")
+        return {k: ms[i] for i, k in enumerate(names)}, {k: n[i] for i, k in enumerate(names)}
+
+
+# ------------------------------------------------------------------------------
+class MigrationInference:
+    """GPU-backed mirror of the reference class (MigrationInference.py:35-739)."""
+    COUNT_LLH = 0
+    CORRECTION_CALLED = 0
+    CORRECTION_FAILED = 0
+
+    def __init__(self, times, lambdas, dataJAFS, splitT, mi=[], pu=[], **kwargs):
+        kw = kwargs
+        self.debug = bool(kw.get("debug", False))
+        self.enableOutput = self.debug or bool(kw.get("enableOutput", False))
+        if self.enableOutput:
+            print("MigrationInference: output enabled.")
+        self.cpfit = bool(kw.get("cpfit", False))
+        self.correct = not bool(kw.get("trueEPS", False))
+        self.smooth = bool(kw.get("smooth", False))
+        self.LLHpsmc = "Tpsmc" in kw
+        if self.LLHpsmc:
+            self.Tpsmc = kw["Tpsmc"]
+        self.unfolded = bool(kw.get("unfolded", False))
+        self.thrh = [1.0, 1.0]
+        if "thrh" in kw and len(kw["thrh"]) == 2:
+            self.thrh = kw["thrh"]
+        self.sampleDate = kw.get("sampleDate", 0)
+        self.mixtureTH = kw.get("mixtureTH", 0.0)
+        self._device = int(kw.get("device", 0))
+        if splitT < self.sampleDate:                                            # :85-86
+            self.PrintError("__init__", "cannot initialise class with split time being more recent than sample date.")
+        self._split_in = float(splitT)
+        self._times0 = [float(v) for v in times]
+        self._lh0 = [[float(l[0]), float(l[1])] for l in lambdas]
+        frac = splitT % 1                                                       # :89-99, incl. the mutation
+        splitT = int(splitT)
+        if splitT - 1 > len(times):
+            self.PrintError("__init__", "Invalid value for split time, cannot create Migration class instance.")
+        if frac != 0.0:
+            t1 = frac * times[splitT]
+            t2 = times[splitT] - t1
+            times[splitT] = t1
+            times.insert(splitT + 1, t2)
+            lambdas.insert(splitT + 1, lambdas[splitT])
+            splitT += 1
+        self.lh = list(lambdas)
+        self.times = times
+        self.numT = len(self.lh)
+        if len(self.times) != self.numT - 1:                                    # :105-107
+            print("Unexpected number of time intervals")
+            raise SystemExit(0)
+        self.discr = 1
+        self.splitT = splitT
+        self.mi = [[None, None] for _ in range(self.numT)]
+        self.pu = [[None, None] for _ in range(self.numT)]
+        self.SetModel(mi, pu)
+        self.SetJAFS(dataJAFS)
+        self.JAFSsize = self.snps
+        self.lc = [[1, 1] for _ in range(self.numT)]
+        self.JAFS = None
+        self.Pr = None
+        self.llh = None
+        self.status = 0
+        self.doPlot = False
+        # bands/pulses in C-ABI form; every band is expressed on this candidate's grid
+        bands = [(pop, start, end, val, -1) for pop, start, end, val in self._fixedMis]
+        bands += [(pop, start, end, val, i) for i, (pop, start, end, val) in enumerate(self.optMis)]
+        n_opt_mi = len(self.optMis)
+        pulses = [(pop, t, val, -1) for pop, t, val in self._fixedPus]
+        pulses += [(pop, t, val, n_opt_mi + i) for i, (pop, t, val) in enumerate(self.optPus)]
+        self._engine = Engine(self._times0, self._lh0, bands, pulses, n_param=n_opt_mi + len(self.optPus),
+                              cpfit=self.cpfit, true_eps=not self.correct, smooth=self.smooth, unfolded=self.unfolded,
+                              sample_date=int(self.sampleDate), mixture_th=float(self.mixtureTH), device=self._device)
+        if self.debug:
+            print("MigrationInference class initialized. Class size", self.numT)
+
+    # -- reference helpers ---------------------------------------------------------
+    def PrintError(self, func, text):                                           # :300-303
+        raise ModelError(func, text)
+
+    def SetJAFS(self, dataJAFS, normalize=False):                               # :202-227
+        if len(dataJAFS) != 8:
+            self.PrintError("SetJAFS", "Unexpected data SFS.")
+        self.snps = sum(dataJAFS[1:])
+        self.dataJAFS = list(dataJAFS[1:])
+        self._row = [float(v) for v in dataJAFS]
+        d = self.dataJAFS
+        c = math.lgamma(self.snps + 1)
+        if self.unfolded:
+            for i in range(7):
+                c -= math.lgamma(d[i] + 1)
+        else:
+            c -= math.lgamma(d[0] + d[6] + 1)
+            c -= math.lgamma(d[1] + d[5] + 1)
+            c -= math.lgamma(d[2] + d[4] + 1)
+            c -= math.lgamma(d[3] + 1)
+        self.llh_const = c
+
+    def SetModel(self, mis, pus):                                               # :229-289
+        self.optMis, self.optPus = [], []
+        self._fixedMis, self._fixedPus = [], []
+        for row in self.mi:
+            row[0] = row[1] = None
+        for row in self.pu:
+            row[0] = row[1] = None
+        for el in mis:
+            popInd = int(el[0]) - 1
+            if popInd != 0 and popInd != 1:
+                self.PrintError("SetModel", "Population index should be 1 or 2.")
+            migStart = int(el[1])
+            if migStart < self.sampleDate:
+                self.PrintError("SetModel", "Migration start (" + str(migStart) + ") should be larger than or equal to sample date (" + str(self.sampleDate) + ").")
+            migEnd = int(el[2])
+            if migEnd <= migStart:
+                self.PrintError("SetModel", "Migration start (" + str(migStart) + ") should be strictly less than migration end (" + str(migEnd) + ").")
+            migVal = float(el[3])
+            migOpt = int(el[4])
+            for i in range(migStart, migEnd):
+                if self.mi[i][popInd] is not None:
+                    self.PrintError("SetModel", "Migration rate intervals should not overlap.")
+                self.mi[i][popInd] = migVal
+            if migOpt == 1:
+                self.optMis.append([popInd, migStart, migEnd, migVal])
+            else:
+                self._fixedMis.append([popInd, migStart, migEnd, migVal])
+        for el in pus:
+            popInd = int(el[0]) - 1
+            if popInd != 0 and popInd != 1:
+                self.PrintError("SetModel", "Population index should be 1 or 2.")
+            puTime = int(el[1])
+            if puTime < self.sampleDate:
+                self.PrintError("SetModel", "Pulse migration time (" + str(puTime) + ") should be larger than or equal to sample date (" + str(self.sampleDate) + ").")
+            puVal = float(el[2])
+            if puVal < 0 or puVal > 1:
+                self.PrintError("SetModel", "Pulse migration rate should be between 0 and 1.")
+            puOpt = int(el[3])
+            if self.pu[puTime][0] is not None or self.pu[puTime][1] is not None:
+                self.PrintError("SetModel", "Current version allows only single-direction pulse migration at a time.")
+            self.pu[puTime][popInd] = puVal
+            if puOpt == 1:
+                self.optPus.append([popInd, puTime, puVal])
+            else:
+                self._fixedPus.append([popInd, puTime, puVal])
+        for arr in (self.mi, self.pu):
+            for row in arr:
+                for k in (0, 1):
+                    if row[k] is None:
+                        row[k] = 0.0
+        self.optMisSize = len(self.optMis)
+        self.optPusSize = len(self.optPus)
+
+    def MapParameters(self, params):                                            # :291-298
+        if len(params) != self.optMisSize + self.optPusSize:
+            self.PrintError("MapParameters", "Incorrect number of parameters.")
+        for i in range(self.optMisSize):
+            for j in range(self.optMis[i][1], self.optMis[i][2]):
+                self.mi[j][self.optMis[i][0]] = params[i]
+        for i in range(self.optPusSize):
+            self.pu[self.optPus[i][1]][self.optPus[i][0]] = params[self.optMisSize + i]
+
+    # -- the hot path ----------------------------------------------------------------
+    def JAFSLikelihood(self, mu):                                               # :566-614
+        cls = MigrationInference
+        cls.COUNT_LLH += 1
+        self.llh = -10 ** 9
+        for v in mu:
+            if v < 0:
+                print("Hit negative value of migration rate")
+                self.status = 1
+                return -np.inf
+        self.MapParameters(mu)
+        cls.CORRECTION_CALLED += 1
+        res = self._engine.evaluate([self._split_in], [list(mu)] if len(mu) else None, [self._row], want_lc=True, want_pr=True)
+        self.status = int(res.status[0])
+        if self.status == 2:
+            cls.CORRECTION_FAILED += 1
+            print("Lambda correction failed")
+            return -np.inf
+        if self.status == 3:
+            self.PrintError("JAFSpectrum", "Infinite coalescent time. No migration.")
+        if self.status != 0:
+            # non-finite intermediate / stiff interval: the candidate has no value here
+            print("MigrationInference: " + STATUS_TEXT.get(self.status, "status %d" % self.status))
+            return -np.inf
+        self.lc = [[float(a), float(b)] for a, b in res.lc[0][: self.numT]]
+        self.Pr = [[[float(r[0]), float(r[1])], [float(r[2]), float(r[3])], [float(r[4]), float(r[5])]]
+                   for r in res.pr[0][: self.splitT + 1]]
+        self.JAFS = [float(v) for v in res.jafs[0]]
+        self.llh = float(res.llk[0, 0])
+        return self.llh
+
+    def JAFSLikelihoodBatch(self, split_times, params=None, jsfs_rows=None, **kw):
+        """Batch form without a reference counterpart: many candidates x replicates in
+        one call on the same grid and band structure (bands ending at this object's
+        split follow each candidate's own split)."""
+        return self._engine.evaluate(split_times, params, [self._row] if jsfs_rows is None else jsfs_rows, **kw)
+
+    def MaximumLLHFunction(self):                                               # :696-711
+        llh = self.llh_const
+        tot = sum(self.dataJAFS)
+        j = [v / tot for v in self.dataJAFS]
+        d = self.dataJAFS
+        if not self.unfolded:
+            llh += (d[0] + d[6]) * math.log(j[0] + j[6])
+            llh += (d[1] + d[5]) * math.log(j[1] + j[5])
+            llh += (d[2] + d[4]) * math.log(j[2] + j[4])
+            llh += d[3] * math.log(j[3])
+        else:
+            for i in range(7):
+                llh += d[i] * math.log(j[i])
+        return llh
+
+    def ObjectiveFunction(self, mu):                                            # :713-716
+        res = -self.JAFSLikelihood(mu)
+        print(mu, res)
+        return res
+
+    def Solve(self, tol=1e-4, globalOpt=False):                                 # :718-733
+        if self.optMisSize + self.optPusSize > 0:
+            from scipy import optimize
+            init = [v[3] for v in self.optMis] + [v[2] for v in self.optPus]
+            if globalOpt:
+                res = optimize.basinhopping(self.ObjectiveFunction, init, T=0.5, minimizer_kwargs=dict(method="Nelder-Mead"))
+            else:
+                res = optimize.minimize(self.ObjectiveFunction, init, method="Nelder-Mead",
+                                        options={"xatol": tol, "fatol": tol, "maxiter": 1000, "disp": True})
+            return [res.x, -res.fun]
+        return [[], self.JAFSLikelihood([])]
+
+    @staticmethod
+    def Report():                                                               # :735-739
+        print("Total number of likelihood function calls is", MigrationInference.COUNT_LLH)
+        print("Lambda correction called", MigrationInference.CORRECTION_CALLED, "times.")
+        print("Lambda correction failed", MigrationInference.CORRECTION_FAILED, "times.")

@@ -57,9 +57,40 @@ def run_reference(times, lambdas, sfs, split, mi, pu, kw, params):
     return rec
 
 
+PERTURB = 2.0 ** -48      # relative input perturbation used to measure the reference's own conditioning
+
+
+def sensitivity(times, lambdas, sfs, split, mi, pu, kw, params, llh):
+    """Amplification of a 2^-48 relative perturbation of the inputs into the
+    reference's log-likelihood: max over three perturbations of
+    |llh' - llh| / |llh| / 2^-48  (None where a perturbed run fails).  The
+    lambda-correction solves stop on SciPy's gtol test after a few finite-difference
+    trust-region steps; where the residual is flat (the pair has all but coalesced
+    inside the interval) the stopping point is decided by rounding noise and the
+    reference's own output is not determined to 1e-9."""
+    worst = 0.0
+    for kind in range(3):
+        if kind == 0:
+            L = [[a * (1 + PERTURB), b * (1 - PERTURB)] for a, b in lambdas]
+            T = list(times)
+        elif kind == 1:
+            L = [[a * (1 - PERTURB), b * (1 + PERTURB)] for a, b in lambdas]
+            T = list(times)
+        else:
+            L = [list(x) for x in lambdas]
+            T = [t * (1 + PERTURB) for t in times]
+        r = run_reference(T, L, sfs, split, mi, pu, kw, params)
+        if r["llh"] is None:
+            return None
+        worst = max(worst, abs(r["llh"] - llh) / abs(llh) / PERTURB)
+    return worst
+
+
 def case(name, times, lambdas, sfs, split, mi=(), pu=(), params=(), **kw):
     t0 = time.time()
     rec = run_reference(times, lambdas, sfs, split, mi, pu, kw, params)
+    if rec["llh"] is not None and name != "tmp":
+        rec["sens"] = sensitivity(times, lambdas, sfs, split, mi, pu, kw, params, rec["llh"])
     return {"name": name,
             "in": {"times": list(times), "lambdas": [list(x) for x in lambdas], "sfs": list(sfs),
                    "split": split, "mi": [list(x) for x in mi], "pu": [list(x) for x in pu],

@@ -1,0 +1,59 @@
+"""HIP path (through the C ABI) against the golden vectors of the reference."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from parity import JAFS_RTOL, LC_RTOL, determined, engine_args, llk_tol, loose_rtol
+
+pytestmark = pytest.mark.gpu
+
+SMALL = load_golden("golden_small")
+SYNTH = load_golden("golden_synthetic")
+
+
+def run_case(case):
+    from misti_amd.engine import MigrationInference
+    args, kw = engine_args(case["in"])
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        m = MigrationInference(*args, **kw)
+        llh = m.JAFSLikelihood(list(case["in"]["params"]))
+    return m, llh, out.getvalue()
+
+
+def check(case):
+    m, llh, text = run_case(case)
+    o = case["out"]
+    assert m.numT == o["numT"] and m.splitT == o["splitT"]
+    assert m.llh_const == pytest.approx(o["llh_const"], rel=1e-14)
+    if o["llh"] is None:
+        assert llh == -np.inf
+        assert o["stdout"][0] in text
+        return
+    if not determined(o):
+        # reference-indeterminate candidate (see tests/parity.py): a failure status or
+        # agreement within the reference's own measured indeterminacy
+        if llh == -np.inf:
+            assert m.status in (2, 5, 6)
+        else:
+            assert abs(llh - o["llh"]) <= loose_rtol(o) * abs(o["llh"]), (llh, o["llh"], o.get("sens"))
+        return
+    np.testing.assert_allclose(np.array(m.lc), np.array(o["lc"]), rtol=LC_RTOL)
+    np.testing.assert_allclose(m.JAFS, o["JAFS"], rtol=JAFS_RTOL)
+    tol = llk_tol(o["llh"], case["in"]["sfs"], o["JAFS"], bool(case["in"]["kw"].get("unfolded")))
+    assert abs(llh - o["llh"]) <= tol, (llh, o["llh"], abs(llh - o["llh"]), tol)
+    if "Pr" in o:
+        np.testing.assert_allclose(np.array(m.Pr), np.array(o["Pr"]), rtol=LC_RTOL, atol=1e-14)
+
+
+@pytest.mark.parametrize("case", SMALL, ids=[c["name"] for c in SMALL])
+def test_small(case):
+    check(case)
+
+
+@pytest.mark.parametrize("case", SYNTH, ids=[c["name"] for c in SYNTH])
+def test_synthetic(case):
+    check(case)
