@@ -54,8 +54,8 @@ extern "C" {
 #define MISTI_INF_COAL       3  /* two-population last interval (:475-476 and splitT == numT) */
 #define MISTI_BAD_STRUCTURE  4  /* band/pulse/split inconsistent for this candidate (reference: PrintError + exit) */
 #define MISTI_NUMERIC        5  /* non-finite intermediate / iteration cap  */
-#define MISTI_STIFF          6  /* an interval with rate x length > 128 (a runaway corrected rate): beyond the
-                                   vector-series path; the reference's own result there is conditioned ~1e-8 */
+#define MISTI_STIFF          6  /* the contour solver for a stiff interval did not converge (very strong
+                                   two-way migration together with a runaway rate) */
 
 #define MISTI_MAX_BANDS   8
 #define MISTI_MAX_PULSES  8

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <complex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -244,6 +245,20 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         std::memcpy(dt.pulse_n, t.pulse_n, sizeof dt.pulse_n);
         std::memcpy(dt.pulse_src, t.pulse_src, sizeof dt.pulse_src);
         std::memcpy(dt.pulse_ab, t.pulse_ab, sizeof dt.pulse_ab);
+        {   // modified Talbot contour z(th) = N[-0.6122 + 0.5017 th cot(0.6407 th) + 0.2645 i th]
+            // (Trefethen, Weideman, Schmelzer 2006), midpoint nodes th_k = -pi + (2k-1) pi/N, upper half
+            const int N = misti::TALBOT_N;
+            const double PI = 3.14159265358979323846;
+            for (int j = 0; j < misti::TALBOT_HALF; ++j) {
+                int k = N / 2 + 1 + j;
+                double th = -PI + (2.0 * k - 1.0) * PI / N;
+                double a = 0.6407 * th;
+                std::complex<double> z(N * (-0.6122 + 0.5017 * th / std::tan(a)), N * 0.2645 * th);
+                std::complex<double> dz(N * (0.5017 / std::tan(a) - 0.5017 * 0.6407 * th / (std::sin(a) * std::sin(a))), N * 0.2645);
+                std::complex<double> cw = std::complex<double>(0.0, 1.0 / N) * std::exp(z) * dz;
+                dt.tal_zr[j] = z.real(); dt.tal_zi[j] = z.imag(); dt.tal_cr[j] = cw.real(); dt.tal_ci[j] = cw.imag();
+            }
+        }
         HIP_TRY(misti::upload_tables(dt));
         // the closed form after the split assumes this one-population generator
         static const int want1[8][8] = {{-6, 0, 0, 0, 0, 0, 0, 0}, {1, -3, 0, 0, 0, 0, 0, 0}, {4, 0, -3, 0, 0, 0, 0, 0}, {1, 0, 0, -3, 0, 0, 0, 0},

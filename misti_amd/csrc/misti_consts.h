@@ -6,5 +6,7 @@ constexpr int NS1 = 8;                // one-population states
 constexpr int MAXNZ = 4;              // off-diagonal entries per generator row
 constexpr int MAXPULSE = 12;          // entries per row of the pulse operator
 constexpr int WAVES_PER_BLOCK = 4;    // candidates per 256-thread workgroup
+constexpr int TALBOT_N = 28;           // nodes of the Talbot contour (conjugate pairs folded: TALBOT_HALF solves)
+constexpr int TALBOT_HALF = TALBOT_N / 2;
 constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
 }  // namespace misti

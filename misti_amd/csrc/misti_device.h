@@ -22,6 +22,8 @@ struct DevTables {
     int pulse_n[2][64];
     int pulse_src[2][64][MAXPULSE];
     int pulse_ab[2][64][MAXPULSE];
+    double tal_zr[TALBOT_HALF], tal_zi[TALBOT_HALF];   // Talbot nodes z_k (upper half plane)
+    double tal_cr[TALBOT_HALF], tal_ci[TALBOT_HALF];   // weights c_k = (i/N) exp(z_k) z'(theta_k)
 };
 
 // Kernel-argument copy of the model (device pointers).

@@ -404,3 +404,14 @@ class MigrationInference:
         print("Total number of likelihood function calls is", MigrationInference.COUNT_LLH)
         print("Lambda correction called", MigrationInference.CORRECTION_CALLED, "times.")
         print("Lambda correction failed", MigrationInference.CORRECTION_FAILED, "times.")
+
+
+def truth_spectrum(times, lh, split, bands, pulses, sample_date, device=0):
+    """Expected JSFS of a fully specified model (``--trueEPS`` route of TestModel.py:95-96)
+    computed on the GPU; used to synthesise data spectra for the workloads."""
+    with Engine(times, lh, bands, pulses, 0, cpfit=True, true_eps=True, smooth=False, unfolded=True,
+                sample_date=sample_date, device=device) as e:
+        r = e.evaluate([float(split)])
+    if int(r.status[0]) != 0:
+        raise MistiError(int(r.status[0]), "truth spectrum failed: " + STATUS_TEXT.get(int(r.status[0]), "?"))
+    return [float(v) for v in r.jafs[0]]

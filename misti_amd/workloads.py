@@ -1,0 +1,142 @@
+"""The configurations of BASELINE.json as concrete synthetic workloads.
+
+Every builder returns a ``Workload``: the merged grid, PSMC-like rates derived
+from a true model (so that the lambda-correction has a solution near the truth),
+band / pulse descriptors in C-ABI form, flags, and the candidate batch.  The data
+JSFS needs the expected spectrum at the truth; the caller supplies
+``spectrum_fn(times, lh, split, bands, pulses, sample_date) -> jafs[7]`` (the HIP
+engine in ``trueEPS`` mode on the GPU box, the oracle in CPU tests).
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import io as mio
+from . import synth
+
+
+@dataclass
+class Workload:
+    name: str
+    times: list
+    lh: list
+    bands: list                 # (pop, start, end(-1 = split), value, param)
+    pulses: list                # (pop, time, value, param)
+    n_param: int
+    flags: dict                 # cpfit / true_eps / smooth / unfolded
+    sample_date: int
+    split_time: np.ndarray      # [n_cand]
+    params: np.ndarray | None   # [n_cand][n_param]
+    truth: dict = field(default_factory=dict)
+    jsfs: np.ndarray | None = None   # [n_rep][8]
+
+    @property
+    def n_cand(self):
+        return int(self.split_time.shape[0])
+
+    @property
+    def numT(self):
+        return len(self.lh)
+
+    def engine_kwargs(self):
+        return dict(bands=self.bands, pulses=self.pulses, n_param=self.n_param, sample_date=self.sample_date, **self.flags)
+
+
+def _truth_bands(bands, split):
+    return [(p, s, split if e < 0 else e, v, -1) for p, s, e, v, _ in bands]
+
+
+def _mis_pus(bands, pulses, split):
+    mis = [[p + 1, s, split if e < 0 else e, v, 0] for p, s, e, v, _ in bands]
+    pus = [[p + 1, t, v, 0] for p, t, v, _ in pulses]
+    return mis, pus
+
+
+def config1(spectrum_fn, n_sites=10 ** 6):
+    """numT = 32, split 20, no migration, a single candidate (plumbing case)."""
+    inp = synth.psmc_pair(16, 17)
+    times, lh, _ = synth.self_consistent(inp, 20)
+    jafs = spectrum_fn(times, lh, 20, [], [], 0)
+    w = Workload("config1: numT=32 split=20 no migration", times, lh, [], [], 0,
+                 dict(cpfit=False, true_eps=False, smooth=True, unfolded=False), 0,
+                 np.array([20.0]), None, dict(split=20))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
+    return w
+
+
+def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0):
+    """numT = 128; grid of split index x rate of one band ``-mi 1 4 {st} {r} 1``, ``--cpfit``."""
+    inp = synth.psmc_pair(64, 65)
+    band_truth = [(0, 4, true_split, true_rate, -1)]
+    mis, pus = _mis_pus(band_truth, [], true_split)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
+    splits = np.arange(first_split, first_split + n_split, dtype=np.float64)
+    rates = np.logspace(-3, np.log10(max_rate), n_rate)
+    st, rr = np.meshgrid(splits, rates, indexing="ij")
+    w = Workload("config2: numT=128, %dx%d split x mi-rate grid, one band, --cpfit" % (n_split, n_rate),
+                 times, lh, [(0, 4, -1, 0.0, 0)], [], 1,
+                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), 0,
+                 st.ravel().copy(), rr.ravel()[:, None].copy(), dict(split=true_split, rate=true_rate))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
+    return w
+
+
+def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6):
+    """Two optimised bands, random starts (one batched simplex-vertex evaluation)."""
+    inp = synth.psmc_pair(64, 65)
+    band_truth = [(0, 4, true_split, 0.2, -1), (1, 10, true_split, 0.05, -1)]
+    mis, pus = _mis_pus(band_truth, [], true_split)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
+    rng = np.random.default_rng(seed)
+    par = 10.0 ** rng.uniform(-3, 0, size=(n_start, 2))
+    w = Workload("config3: numT=128, two optimised bands, %d random starts, --cpfit" % n_start,
+                 times, lh, [(0, 4, true_split, 0.1, 0), (1, 10, true_split, 0.1, 1)], [], 2,
+                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), 0,
+                 np.full(n_start, float(true_split)), par, dict(split=true_split))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
+    return w
+
+
+def config4(spectrum_fn, n_split=256, n_rep=1000, true_split=50, cpfit=False, seed=3, n_sites=10 ** 6):
+    """No migration; split scan incl. fractional values x bootstrap replicates
+    (test.bs/*no.mig.sh shape; replicate table as utils/generateJSFS_bs.py writes it)."""
+    inp = synth.psmc_pair(64, 65)
+    times, lh, _ = synth.self_consistent(inp, true_split)
+    jafs = spectrum_fn(times, lh, true_split, [], [], 0)
+    row = synth.counts_from_spectrum(jafs, n_sites)
+    table = mio.bootstrap_table(synth.chunk_rows(row, 20), n_rep - 1, random.Random(seed))
+    splits = 20.0 + 0.25 * np.arange(n_split)
+    w = Workload("config4: numT=128, no migration, %d split values x %d bootstrap replicates" % (n_split, n_rep),
+                 times, lh, [], [], 0, dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
+                 splits, None, dict(split=true_split))
+    w.jsfs = np.array(table, dtype=np.float64)
+    return w
+
+
+def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true_split=80, n_sites=10 ** 6):
+    """Ancient second genome (--sdate 40000) + --hetloss 0 0.1; split x band rate x pulse fraction."""
+    inp = synth.psmc_pair(64, 64, sample_date=40000.0, units=mio.Units(hetloss2=0.1))
+    sd = inp.sampleDateDiscr
+    band_truth = [(0, sd + 2, true_split, 0.15, -1)]
+    pulse_truth = [(1, sd + 10, 0.1, -1)]
+    mis, pus = _mis_pus(band_truth, pulse_truth, true_split)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    jafs = spectrum_fn(times, lh, true_split, band_truth, pulse_truth, sd)
+    splits = np.arange(first_split, first_split + n_split, dtype=np.float64)
+    rates = np.logspace(-3, 0, n_rate)
+    fr = np.linspace(0.0, 0.5, n_pulse)
+    a, b, c = np.meshgrid(splits, rates, fr, indexing="ij")
+    w = Workload("config5: numT=128 sdate=40000 hetloss=(0,0.1), %dx%dx%d split x mi x pu grid, --cpfit" % (n_split, n_rate, n_pulse),
+                 times, lh, [(0, sd + 2, -1, 0.0, 0)], [(1, sd + 10, 0.0, 1)], 2,
+                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), sd,
+                 a.ravel().copy(), np.stack([b.ravel(), c.ravel()], axis=1), dict(split=true_split, sample_date=sd))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
+    return w
+
+
+BUILDERS = {"config1": config1, "config2": config2, "config3": config3, "config4": config4, "config5": config5}

@@ -542,6 +542,11 @@ class OracleModel:
         self.Pr = [[[1.0, 0.0], [0.0, 1.0], [0.0, 0.0]]]
         nc = [0, 0]
         cl = self.cl
+        # Diagnostic, not part of the reference: largest corrected rate x interval length before
+        # smoothing.  Beyond ~30 the pair has coalesced to 1e-13 inside the interval, the
+        # correction's residual is flat in that rate and SciPy's solver stops where rounding noise
+        # in its finite-difference Jacobian lets the gradient test pass ("runaway" rate).
+        self.max_rate_x_len = 0.0
         for t in range(self.splitT):
             p0 = _pulse_pairs(p0, self.pu[t])
             cl.set_mu(self.mi[t][0], self.mi[t][1])
@@ -553,6 +558,7 @@ class OracleModel:
                 self.lc[t] = [sol[0][0], sol[0][1]]
                 if sol[0][0] <= 0 or sol[0][1] <= 0:
                     return False
+                self.max_rate_x_len = max(self.max_rate_x_len, sol[0][0] * self.times[t], sol[0][1] * self.times[t])
                 p0 = sol[1]
             self.Pr.append([[p0[0][0], p0[1][0]], [p0[0][1], p0[1][1]], [p0[0][2], p0[1][2]]])
             nc = [sum(p0[0]), sum(p0[1])]   # a probability here, used as a log below (:353-354)

@@ -1,0 +1,127 @@
+"""CPU-side tests: readers against the reference's own reader dumps, C-ABI library
+loads and exports every declared symbol, the product path fails loudly without a GPU."""
+import ctypes as C
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+from misti_amd import _lib, io as mio, synth
+
+
+def reader_cases():
+    return json.load(open(os.path.join(GOLDEN, "golden_readers.json")))["cases"]
+
+
+@pytest.mark.parametrize("k", range(4))
+def test_read_psmc_matches_reference_dump(k):
+    c = reader_cases()[k]
+    hl = c["hetloss"] or (0.0, 0.0)
+    u = mio.Units(hetloss1=hl[0], hetloss2=hl[1])
+    d = mio.merge_psmc(mio.read_psmc_file(io.StringIO(c["psmc1"])), mio.read_psmc_file(io.StringIO(c["psmc2"])), c["sdate"], u)
+    assert d.times == c["times"]
+    assert d.lambdas == c["lambdas"]
+    assert d.sampleDateDiscr == c["sampleDateDiscr"]
+    assert d.Tpsmc == c["Tpsmc"]
+    assert d.theta == c["theta"] and d.rho == c["rho"] and d.scaleTime == c["scaleTime"]
+
+
+def test_psmc_round_selection_and_errors():
+    t = synth.psmc_text(8, 3, 0.05, rounds=3)
+    a = mio.read_psmc_file(io.StringIO(t), rd=-1)
+    b = mio.read_psmc_file(io.StringIO(t), rd=99)
+    c = mio.read_psmc_file(io.StringIO(t), rd=0)
+    assert a[2] == 2 and b[2] == 2 and c[2] == 0 and a[:2] != c[:2]
+    with pytest.raises(mio.FormatError):
+        mio.read_psmc_file(io.StringIO("XX 1\n"))
+
+
+def test_jsfs_roundtrip_and_bootstrap():
+    rows = [[1000.0, 10, 20, 30, 40, 50, 60, 70], [900.0, 1, 2, 3, 4, 5, 6, 7]]
+    text = mio.format_jsfs(rows, "popA", "popB")
+    back, p1, p2 = mio.read_jsfs(io.StringIO(text))
+    assert back == rows and p1 == "popA" and p2 == "popB"
+    assert text.splitlines()[0] == "#MiSTI_JSFS version 1.0"
+    assert mio.format_jsfs([[1, 2, 3, 4, 5, 6, 7]]).splitlines()[-1].split("\t")[0] == "28"
+    import random
+    tab = mio.bootstrap_table(rows, 5, random.Random(1))
+    assert len(tab) == 6 and tab[0] == [1900.0, 11, 22, 33, 44, 55, 66, 77]
+    for r in tab[1:]:
+        assert r[0] >= 1900.0                       # resampled up to the genome length (BootstrapJAFS :516)
+    with pytest.raises(mio.FormatError):
+        mio.read_jsfs(io.StringIO("#wrong header\n"))
+    with pytest.raises(mio.FormatError):
+        mio.read_jsfs(io.StringIO("#MiSTI_JSFS version 1.0\ntotal\n1\t2\n"))
+
+
+def test_units_file(tmp_path):
+    f = tmp_path / "u.txt"
+    f.write_text("mutRate=2.5e-8\nbinsize=100\nN0=5000\ngenTime=29\njunk\n")
+    u = mio.Units.from_file(str(f))
+    assert (u.mutRate, u.binsize, u.N0, u.genTime) == (2.5e-8, 100.0, 5000.0, 29.0)
+    assert mio.Units.from_file(str(tmp_path / "missing")).N0 == 10000
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/misti_hip.h resolves in the built .so."""
+    hdr = open(os.path.join(ROOT, "include", "misti_hip.h")).read()
+    declared = set(re.findall(r"\b(misti_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.misti_abi_version() == 1
+
+
+def test_tables_match_oracle_structure():
+    """The library's own derivation of the 44-state chain equals the oracle's."""
+    from oracle.misti_oracle import TWO_POP
+    lib = _lib.load()
+    gen = np.zeros((4, 44, 44), np.int32)
+    jaf = np.zeros((44, 7), np.int32)
+    assert lib.misti_tables(gen.ctypes.data_as(C.POINTER(C.c_int32)), jaf.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert (gen[0] == TWO_POP.A[0]).all() and (gen[1] == TWO_POP.A[1]).all()
+    assert (gen[2] == TWO_POP.B[0]).all() and (gen[3] == TWO_POP.B[1]).all()
+    assert (jaf == TWO_POP.jaf).all()
+    assert [int((g != 0).sum()) for g in gen] == [44, 44, 88, 88]
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from misti_amd.engine import Engine, MigrationInference
+    with pytest.raises(_lib.MistiError) as e:
+        Engine([0.1, 0.2], [[1, 1], [1, 1], [1, 1]])
+    assert e.value.code == -3
+    with pytest.raises(_lib.MistiError):
+        MigrationInference([0.1, 0.2], [[1, 1], [1, 1], [1, 1]], [10, 1, 1, 1, 1, 1, 1, 1], 1)
+
+
+def test_model_validation_messages():
+    """Argument errors come back as codes + messages, never exit()."""
+    lib = _lib.load()
+    times = (C.c_double * 2)(0.1, 0.2)
+    lh = (C.c_double * 6)(1, 1, 1, 1, 1, 1)
+    band = (_lib.Band * 1)(_lib.Band(0, 2, 1, -1, 0.5))
+    m = _lib.Model(3, 0, 0, 1, 0, 0, 0.0, times, lh, band, None)
+    ctx = C.c_void_p()
+    rc = lib.misti_create(C.byref(m), 0, C.byref(ctx))
+    assert rc == -1 and b"strictly less" in lib.misti_last_error()
+    m2 = _lib.Model(1, 0, 0, 0, 0, 0, 0.0, times, lh, None, None)
+    assert lib.misti_create(C.byref(m2), 0, C.byref(ctx)) == -1
+
+
+def test_product_never_imports_oracle():
+    """No module of the product package may reference the oracle."""
+    pkg = os.path.join(ROOT, "misti_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                text = open(os.path.join(base, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
