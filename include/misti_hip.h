@@ -133,7 +133,9 @@ int misti_sync(misti_ctx* ctx);
  *   lc         [n_cand][numT+1][2] or NULL   corrected rates (.lc); row numT is used
  *                                  only by a fractional split; unused rows = 0
  *   pr         [n_cand][numT+2][6] or NULL   pair-state trace (.Pr, :309,:350):
- *                                  row t = p11 g1,g2, p22 g1,g2, p12 g1,g2
+ *                                  row t = p11 g1,g2, p22 g1,g2, p12 g1,g2; the last row (numT+1)
+ *                                  carries work counters of the correction: residual batches,
+ *                                  dense (stiff) exponentials, series terms, squarings, max nfev
  *   status     [n_cand]     or NULL   MISTI_OK / MISTI_NEG_PARAM / ...
  */
 int misti_eval_batch(misti_ctx* ctx, int64_t n_cand,

@@ -44,9 +44,9 @@ struct DevModel {
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
-                          double* lc, double* pr, int32_t* status, hipStream_t stream);
+                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
-                           const double* lc, double* jafs, int32_t* status, hipStream_t stream);
+                           const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
                       const double* consts, double* llk, int unfolded, hipStream_t stream);

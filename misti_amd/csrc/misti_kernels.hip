@@ -32,6 +32,7 @@
 namespace misti {
 
 __constant__ DevTables c_tab;
+__constant__ double c_inv[INV_TABLE];   // c_inv[k] = 1/k: series terms divide by k (an fp64 division costs ~40 instructions)
 
 // exp(M T) P0 and the occupation integral per interval, two methods:
 //  * q = (largest exit rate) x (interval length) <= Q_SWITCH: uniformisation series
@@ -50,6 +51,12 @@ constexpr int JACOBI_MAX = 600;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+// The correction kernel packs GROUP lanes per candidate (6 of them carry the residual
+// evaluations: 3 forward-difference points x 2 genomes), i.e. 8 candidates per wavefront.
+// Everything "uniform" is uniform within a group; cross-lane traffic never leaves a group.
+constexpr int GROUP = 8;
+__device__ __forceinline__ double gbcast(double v, int j) { return __shfl(v, (lane_id() & ~(GROUP - 1)) + j, 64); }
 
 __device__ __forceinline__ void lds_fence() {
     // one wave owns its LDS slice: ordering only has to be kept by the compiler
@@ -121,7 +128,9 @@ struct Model {
 //     [  2mu0      2mu1    -mu0-mu1  ]
 // v <- exp(M) v by uniformisation.  Every lane carries its own (l, v); the trip
 // count is wave-uniform (bound from the largest q in the wave).
-__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], bool active, bool& guard) {
+// Per-candidate diagnostics of the correction: overflow guard and work counters.
+struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0; };
+__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], bool active, Diag& dg) {
     bool ok = isfinite(l0) && isfinite(l1);
     if (!active || !ok) { l0 = 0.0; l1 = 0.0; }
     double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1;
@@ -130,12 +139,13 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
     // rate with one-directional migration) the forward-difference lanes then perform
     // bit-identical arithmetic on the remaining components, so the Jacobian column is
     // exactly zero - as it is in the reference, whose solver leaves that rate untouched.
+    // ("wave" = the GROUP lanes of one candidate.)
     double q = fmax(fmax(d0, d1), fmax(d2, 0.0));
     double neg = fmax(0.0, fmax(-l0, -l1));
-    for (int o = 32; o > 0; o >>= 1) { q = fmax(q, __shfl_xor(q, o, 64)); neg = fmax(neg, __shfl_xor(neg, o, 64)); }
+    for (int o = GROUP / 2; o > 0; o >>= 1) { q = fmax(q, __shfl_xor(q, o, 64)); neg = fmax(neg, __shfl_xor(neg, o, 64)); }
     double nbmax = q + neg;                                  // >= ||N||_1 (column sums q - l0, q - l1, q)
     if (!(nbmax < 1e300)) {                                  // overflowing iterate: report non-finite (TRF shrinks the step)
-        guard = true;
+        dg.guard = true;
         if (active) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
@@ -144,11 +154,12 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         // vanishes): dense scaling and squaring of the 3x3 matrix, degree-12 Taylor kernel
         int sq = 0;
         { double nrm = 2.0 * nbmax; while (nrm > 0.25) { nrm *= 0.5; ++sq; } }
+        dg.dense += 1; dg.squarings += sq;
         double scl = ldexp(1.0, -sq);
         double B[3][3] = {{-d0 * scl, 0.0, mu1 * scl}, {0.0, -d1 * scl, mu0 * scl}, {2.0 * mu0 * scl, 2.0 * mu1 * scl, -d2 * scl}};
         double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
         for (int k = 12; k >= 1; --k) {                      // E = I + B E / k
-            double inv = 1.0 / (double)k;
+            double inv = c_inv[k];
             double Tm[3][3];
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
                 Tm[r][c] = ((B[r][0] * E[0][c] + B[r][1] * E[1][c]) + B[r][2] * E[2][c]) * inv;
@@ -178,13 +189,14 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         double a0 = p0, a1 = p1, a2 = p2;
         double b = 1.0;                    // nbs^k / k! bounds the k-th term for every lane
         for (int k = 1; k < 200; ++k) {
-            double inv = 1.0 / (double)k;
+            double inv = c_inv[k];
             double t0 = (n00 * p0 + n02 * p2) * inv;
             double t1 = (n11 * p1 + n12 * p2) * inv;
             double t2 = (n20 * p0 + n21 * p1 + n22 * p2) * inv;
             p0 = t0; p1 = t1; p2 = t2;
             a0 += p0; a1 += p1; a2 += p2;
             b *= nbs * inv;
+            dg.terms += 1;
             if (b < 1e-19 && (double)k > nbs) break;
         }
         v[0] = a0; v[1] = a1; v[2] = a2;
@@ -555,7 +567,7 @@ __device__ __forceinline__ double ect_noncond(double lam, double T) { return (1.
 
 // Residuals of the migrating two-population interval, evaluated for the base
 // point and both forward-difference points in one wave pass.
-// lane = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
+// lane (within the candidate's group) = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
 struct PairProblem {
     double mu0, mu1;       // stretched to unit interval (CorrectLambda.py:293-298)
     double lh0, lh1;       // stretched
@@ -568,7 +580,8 @@ struct PairEval {
     double v[2][3];        // exp(M) P[k] at the base point
     bool finite;
 };
-__device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, double x1, int lane, bool& guard) {
+template <bool CPFIT>
+__device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, double x1, int lane, Diag& dg) {
     double h0 = fd_step(x0), h1 = fd_step(x1);
     double xa = x0 + h0, xb = x1 + h1;
     double dx0 = xa - x0, dx1 = xb - x1;            // recomputed as exactly representable (_numdiff.py)
@@ -581,10 +594,12 @@ __device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, 
     for (int i = 0; i < 3; ++i) { v[i] = k ? pb.P[1][i] : pb.P[0][i]; }
     s = (v[0] + v[1]) + v[2];
     double res;
-    if (pb.cpfit) {
+    if (CPFIT) {
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
         double w[3] = {v[0], v[1], v[2]};
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, guard);
+#if !defined(MISTI_ABLATE) || MISTI_ABLATE != 2
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, dg);
+#endif
         double nch = exp(-(k ? pb.lh1 : pb.lh0)) * s;
         res = ((w[0] + w[1]) + w[2]) - nch;
         v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
@@ -592,7 +607,7 @@ __device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, 
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
         double pn[3] = {v[0] / s, v[1] / s, v[2] / s};
         double w[3] = {pn[0], pn[1], pn[2]};
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, guard);
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, dg);
         double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
         double d[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
         double y[3], vec1[3], vec2[3];
@@ -609,27 +624,32 @@ __device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, 
         v[0] = w[0] * s; v[1] = w[1] * s; v[2] = w[2] * s;
     }
     PairEval o;
-    double fb0 = bcast(res, 0), fb1 = bcast(res, 1);
-    double fa0 = bcast(res, 2), fa1 = bcast(res, 3);
-    double fc0 = bcast(res, 4), fc1 = bcast(res, 5);
+    double fb0 = gbcast(res, 0), fb1 = gbcast(res, 1);
+    double fa0 = gbcast(res, 2), fa1 = gbcast(res, 3);
+    double fc0 = gbcast(res, 4), fc1 = gbcast(res, 5);
     o.f[0] = fb0; o.f[1] = fb1;
     o.J[0][0] = (fa0 - fb0) / dx0; o.J[1][0] = (fa1 - fb1) / dx0;
     o.J[0][1] = (fc0 - fb0) / dx1; o.J[1][1] = (fc1 - fb1) / dx1;
-    for (int i = 0; i < 3; ++i) { o.v[0][i] = bcast(v[i], 0); o.v[1][i] = bcast(v[i], 1); }
+    for (int i = 0; i < 3; ++i) { o.v[0][i] = gbcast(v[i], 0); o.v[1][i] = gbcast(v[i], 1); }
     o.finite = isfinite(fb0) && isfinite(fb1);
     return o;
 }
 
 // trf_no_bounds (trf.py:401-560) on the residual above.  Returns x and the
 // propagated pair vectors exp(M(x)) P[k] (CorrectLambda.py:313-317).
-__device__ __forceinline__ void trf2_unbounded(const PairProblem& pb, double x[2], double vout[2][3], int lane, bool& guard) {
-    PairEval ev = pair_eval(pb, x[0], x[1], lane, guard);
+template <bool CPFIT>
+__device__ __forceinline__ void trf2_unbounded(const PairProblem& pb, double x[2], double vout[2][3], int lane, Diag& dg) {
+    PairEval ev = pair_eval<CPFIT>(pb, x[0], x[1], lane, dg);
     double f[2] = {ev.f[0], ev.f[1]};
     double J[2][2] = {{ev.J[0][0], ev.J[0][1]}, {ev.J[1][0], ev.J[1][1]}};
     for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) vout[k][i] = ev.v[k][i];
     int nfev = 1;
     const int max_nfev = 200;
     double cost = 0.5 * (f[0] * f[0] + f[1] * f[1]);
+    struct Tally { Diag& d; int& n; __device__ ~Tally() { d.evals += n; d.max_nfev = n > d.max_nfev ? n : d.max_nfev; } } tally{dg, nfev};
+#if defined(MISTI_ABLATE) && MISTI_ABLATE == 1
+    return;
+#endif
     double g[2] = {J[0][0] * f[0] + J[1][0] * f[1], J[0][1] * f[0] + J[1][1] * f[1]};
     double Delta = sqrt(x[0] * x[0] + x[1] * x[1]);
     if (Delta == 0) Delta = 1.0;
@@ -650,7 +670,7 @@ __device__ __forceinline__ void trf2_unbounded(const PairProblem& pb, double x[2
             double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
             double predicted = -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
             xn[0] = x[0] + p[0]; xn[1] = x[1] + p[1];
-            en = pair_eval(pb, xn[0], xn[1], lane, guard);
+            en = pair_eval<CPFIT>(pb, xn[0], xn[1], lane, dg);
             ++nfev;
             double step_norm = sqrt(p[0] * p[0] + p[1] * p[1]);
             if (!en.finite) { Delta = 0.25 * step_norm; continue; }
@@ -693,9 +713,10 @@ __device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu
 }
 
 // One interval of SolveLambdaSystem (CorrectLambda.py:266-317); lc < 0 signals failure.
+template <bool CPFIT>
 __device__ __forceinline__ void correct_interval(const DevModel& m, double lh0, double lh1, double T, double mu0, double mu1,
-                                                 PairState& ps, double lc[2], int lane, bool& guard) {
-    const bool cpfit = m.flags & MISTI_CPFIT;
+                                                 PairState& ps, double lc[2], int lane, Diag& dg) {
+    constexpr bool cpfit = CPFIT;
     double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
     double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
     double mix = 0.0;
@@ -747,7 +768,7 @@ __device__ __forceinline__ void correct_interval(const DevModel& m, double lh0, 
     pb.cpfit = cpfit;
     double x[2] = {pb.lh0, pb.lh1};
     double v[2][3];
-    trf2_unbounded(pb, x, v, lane, guard);
+    trf2_unbounded<CPFIT>(pb, x, v, lane, dg);
     lc[0] = x[0] / T; lc[1] = x[1] / T;                                              // :312
     for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) ps.p[k][i] = v[k][i];
 }
@@ -772,38 +793,33 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
     return status;
 }
 
-// Kernel 1: lambda correction (CorrectLambdas + Smooth, MigrationInference.py:305-405).
-// One wave per candidate; writes the corrected rates lc[cand][numT+1][2], the
-// pair-state trace and the status.  LDS per wave (doubles): lc[2*(numT0+1)].
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+// Kernel 1: lambda correction of the two-population intervals (CorrectLambdas loop t < splitT,
+// MigrationInference.py:307-354).  GROUP lanes per candidate, 8 candidates per wavefront, no LDS.
+// Writes the unsmoothed corrected rates of the two-population intervals lc_raw[cand][numT+1][2],
+// the non-coalescence sums nc[cand][2] at the split (:353-354), the pair-state trace, the status.
+template <bool CPFIT>
+__global__ __launch_bounds__(64)
 void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
-                    double* __restrict__ lc_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
-    extern __shared__ double lds[];
+                    double* __restrict__ lc_raw, double* __restrict__ nc_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int sub = lane & (GROUP - 1);
+    const int64_t cand = ((int64_t)blockIdx.x * (64 / GROUP)) + (lane / GROUP);
     if (cand >= n_cand) return;
     const int lc_rows = m.numT + 1;
-    double* lcb = lds + (size_t)wave * (2 * lc_rows);
-
     const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
     int status = setup_candidate(m, split_time[cand], par, G);
     Model mod{&m, par, G.split};
-    for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = 0.0;
-    lds_fence();
-
     const bool correct = !(m.flags & MISTI_TRUE_EPS);
-    const bool cpfit = m.flags & MISTI_CPFIT;
     double* pr_c = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
+    double* lc_c = lc_raw + cand * (int64_t)lc_rows * 2;
 
-    // ---- lambda correction, two-population part (:307-354) -------------------
-    bool guard = false;     // an absurd solver iterate was cut off (results would differ from the reference)
+    Diag dg;                // overflow guard + work counters
     PairState ps;
     ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
     ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
     if (status == MISTI_OK) {
-        if (pr_c && lane == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
+        if (pr_c && sub == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
         for (int t = 0; t < G.split; ++t) {
             double pu0, pu1, mu0, mu1;
             mod.pulse(t, pu0, pu1);
@@ -812,26 +828,74 @@ void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
             double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
             double lc[2] = {lh0, lh1};
             if (correct) {
-                correct_interval(m, lh0, lh1, G.T(t), mu0, mu1, ps, lc, lane, guard);
+                correct_interval<CPFIT>(m, lh0, lh1, G.T(t), mu0, mu1, ps, lc, sub, dg);
                 if (!(lc[0] > 0) || !(lc[1] > 0)) {                                    // :346-348 (NaN fails too)
                     status = (isnan(lc[0]) || isnan(lc[1])) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
+                    if (sub == 0) { lc_c[2 * t] = lc[0]; lc_c[2 * t + 1] = lc[1]; }
                     break;
                 }
             }
-            if (lane == 0) { lcb[2 * t] = lc[0]; lcb[2 * t + 1] = lc[1]; }
-            if (pr_c && lane == 0) {
+            if (sub == 0) { lc_c[2 * t] = lc[0]; lc_c[2 * t + 1] = lc[1]; }
+            if (pr_c && sub == 0) {
                 double* r = pr_c + 6 * (t + 1);
                 r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
             }
         }
     }
-    if (status == MISTI_OK) {
-        lds_fence();
-        // ---- post-split rates (:353-376); nc is a probability used as a log ----
-        double nc0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
-        double nc1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
-        double delta = nc1 - nc0;
-        double ed = exp(delta);
+    if (status == MISTI_OK && dg.guard) status = MISTI_NUMERIC;
+    if (pr_c && sub == 0) {                       // last row of the trace buffer: work counters of this candidate
+        double* r = pr_c + 6 * (m.numT + 1);
+        r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = 0.0;
+    }
+    if (sub == 0) {
+        status_out[cand] = status;
+        nc_out[2 * cand] = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];       // :353-354: a probability, used as a log below
+        nc_out[2 * cand + 1] = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
+    }
+}
+
+// Kernel 2: post-split rates (:355-376), Smooth (:380-405) and the expected joint spectrum
+// (JAFSpectrum, :467-540).  One wavefront per candidate; lane = interval in the prologue,
+// lane = state of the 44-state chain afterwards.
+// LDS per wave (doubles): xbuf[128] (re | im) | lc[2*(numT0+1)]
+template <bool CPFIT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
+                     const double* __restrict__ lc_raw, const double* __restrict__ nc_in, double* __restrict__ lc_out,
+                     double* __restrict__ jafs_out, int32_t* __restrict__ status_io) {
+    extern __shared__ double lds[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (cand >= n_cand) return;
+    const int lc_rows = m.numT + 1;
+    double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
+    double* lcb = xbuf + 128;
+    int status = status_io[cand];
+    const double* par = params ? params + cand * m.n_param : nullptr;
+    Grid G;
+    (void)setup_candidate(m, split_time[cand], par, G);
+    Model mod{&m, par, G.split};
+    double* lc_o = lc_out ? lc_out + cand * (int64_t)lc_rows * 2 : nullptr;
+    if (status != MISTI_OK) {
+        if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
+        if (lc_o) {                          // partial rates (up to the failing interval) for diagnostics
+            const double* src = lc_raw + cand * (int64_t)lc_rows * 2;
+            int upto = (status == MISTI_CORR_FAILED || status == MISTI_NUMERIC) ? 2 * G.split : 0;
+            for (int i = lane; i < 2 * lc_rows; i += 64) lc_o[i] = (i < upto && i < 2 * m.numT) ? src[i] : 0.0;
+        }
+        return;
+    }
+    {
+        const double* src = lc_raw + cand * (int64_t)lc_rows * 2;
+        for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = (i < 2 * G.split) ? src[i] : 0.0;
+    }
+    lds_fence();
+    {
+        // ---- post-split rates (:355-376); nc is a probability used as a log ----
+        const double nc0 = nc_in[2 * cand], nc1 = nc_in[2 * cand + 1];
+        const double delta = nc1 - nc0;
+        const double ed = exp(delta);
         const int last = G.numT - 1;
         for (int base = G.split; base < G.numT; base += 64) {
             int t = base + lane;
@@ -840,7 +904,7 @@ void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
                 double lam = 1.0;
                 if (T != 0) {
                     double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
-                    if (cpfit) {
+                    if (CPFIT) {
                         double pnc = (exp(-T * lh0) + exp(delta - T * lh1)) / (1.0 + ed);   // :366
                         lam = -log(pnc) / T;
                     } else {
@@ -890,44 +954,9 @@ void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
             lds_fence();
         }
         for (int i = lane; i < 2 * G.numT; i += 64) { double v = lcb[i]; if (!(v == v)) status = MISTI_NUMERIC; }
-        status = (guard || __any(status != MISTI_OK)) ? MISTI_NUMERIC : MISTI_OK;
+        status = __any(status != MISTI_OK) ? MISTI_NUMERIC : MISTI_OK;
+        if (lc_o) for (int i = lane; i < 2 * lc_rows; i += 64) lc_o[i] = (i < 2 * G.numT) ? lcb[i] : 0.0;
     }
-
-    // ---- outputs ------------------------------------------------------------
-    if (lane == 0) status_out[cand] = status;
-    lds_fence();
-    double* o = lc_out + cand * (int64_t)lc_rows * 2;
-    for (int i = lane; i < 2 * lc_rows; i += 64) o[i] = (i < 2 * G.numT) ? lcb[i] : 0.0;   // partial (up to the failing interval) when status != OK
-}
-
-// Kernel 2: expected joint spectrum (JAFSpectrum, MigrationInference.py:467-540).
-// One wave per candidate, lane = state of the 44-state chain.
-// LDS per wave (doubles): xbuf[128] (re | im) | lc[2*(numT0+1)]
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
-void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
-                     const double* __restrict__ lc_in, double* __restrict__ jafs_out, int32_t* __restrict__ status_io) {
-    extern __shared__ double lds[];
-    const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (cand >= n_cand) return;
-    const int lc_rows = m.numT + 1;
-    double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
-    double* lcb = xbuf + 128;
-    int status = status_io[cand];
-    if (status != MISTI_OK) {
-        if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
-        return;
-    }
-    const double* par = params ? params + cand * m.n_param : nullptr;
-    Grid G;
-    (void)setup_candidate(m, split_time[cand], par, G);
-    Model mod{&m, par, G.split};
-    {
-        const double* src = lc_in + cand * (int64_t)lc_rows * 2;
-        for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = src[i];
-    }
-    lds_fence();
     double jafs[7] = {0, 0, 0, 0, 0, 0, 0};
 
     if (status == MISTI_OK) {
@@ -989,8 +1018,8 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ spli
                 double p = eq * x, ii = 0.0;
                 double accp = p, acci = 0.0;
                 double b = eq, bprev = 1.0;
-                for (int k = 1; k < 1000; ++k) {
-                    double inv = 1.0 / (double)k;
+                for (int k = 1; k < INV_TABLE; ++k) {
+                    double inv = c_inv[k];
                     xbuf[lane] = p;
                     lds_fence();
                     double r0 = xbuf[srcl[0]], r1 = xbuf[srcl[1]], r2 = xbuf[srcl[2]], r3 = xbuf[srcl[3]];
@@ -1173,26 +1202,39 @@ void llk_kernel(int64_t n_cand, const double* __restrict__ jafs, const int32_t* 
 }
 
 // ----------------------------------------------------------- launchers -------
-hipError_t upload_tables(const DevTables& t) { return hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(DevTables)); }
+hipError_t upload_tables(const DevTables& t) {
+    static double inv[INV_TABLE];
+    inv[0] = 0.0;
+    for (int k = 1; k < INV_TABLE; ++k) inv[k] = 1.0 / (double)k;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_inv), inv, sizeof inv);
+    if (e != hipSuccess) return e;
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(DevTables));
+}
 
-size_t correct_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (2 * (numT + 1)) * sizeof(double); }
 size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
 
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
-                          double* lc, double* pr, int32_t* status, hipStream_t stream) {
+                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
-    dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    hipLaunchKernelGGL(correct_kernel, grid, dim3(WAVES_PER_BLOCK * 64), correct_lds_bytes(m.numT), stream,
-                       m, n_cand, split, params, lc, pr, status);
+    const int per_wave = 64 / GROUP;
+    dim3 grid((unsigned)((n_cand + per_wave - 1) / per_wave));
+    if (m.flags & MISTI_CPFIT)
+        hipLaunchKernelGGL(correct_kernel<true>, grid, dim3(64), 0, stream, m, n_cand, split, params, lc_raw, nc, pr, status);
+    else
+        hipLaunchKernelGGL(correct_kernel<false>, grid, dim3(64), 0, stream, m, n_cand, split, params, lc_raw, nc, pr, status);
     return hipGetLastError();
 }
 
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
-                           const double* lc, double* jafs, int32_t* status, hipStream_t stream) {
+                           const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    hipLaunchKernelGGL(spectrum_kernel, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                       m, n_cand, split, params, lc, jafs, status);
+    if (m.flags & MISTI_CPFIT)
+        hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
+                           m, n_cand, split, params, lc_raw, nc, lc_out, jafs, status);
+    else
+        hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
+                           m, n_cand, split, params, lc_raw, nc, lc_out, jafs, status);
     return hipGetLastError();
 }
 

@@ -1,0 +1,76 @@
+"""The MiSTI.py-compatible command line end to end on synthetic files (config 1 of
+BASELINE.json: numT = 32, split 20, no migration, single likelihood) and an optimised band."""
+import io
+import os
+import re
+import contextlib
+
+import numpy as np
+import pytest
+
+from parity import llk_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def write_inputs(tmp_path, n1=16, n2=17):
+    from misti_amd import synth, io as mio
+    from oracle.batch import oracle_truth_spectrum
+    f1, f2, fj = (str(tmp_path / n) for n in ("g1.psmc", "g2.psmc", "data.sfs"))
+    open(f1, "w").write(synth.psmc_text(n1, 1, synth.THETA_1))
+    open(f2, "w").write(synth.psmc_text(n2, 2, synth.THETA_2))
+    inp = mio.read_psmc(f1, f2)
+    jafs = oracle_truth_spectrum(inp.times, inp.lambdas, 20, [], [], 0)
+    row = synth.counts_from_spectrum(jafs, 200000)
+    open(fj, "w").write(mio.format_jsfs(synth.chunk_rows(row, 5)))
+    return f1, f2, fj, inp, row
+
+
+def run_cli(args):
+    from misti_amd import cli
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        rc = cli.main(args)
+    return rc, out.getvalue()
+
+
+def test_single_likelihood_matches_oracle(tmp_path):
+    from oracle.misti_oracle import OracleModel
+    f1, f2, fj, inp, row = write_inputs(tmp_path)
+    units = str(tmp_path / "nounits.txt")
+    rc, text = run_cli([f1, f2, fj, "20", "--funits", units])
+    assert rc == 0
+    m = re.search(r"bs_id = -1 \tsplitT = 20.0 \ttime = (\S+) \tmigration rates  \tllh = (\S+)", text)
+    assert m, text
+    llh = float(m.group(2))
+    o = OracleModel(inp.times, inp.lambdas, row, 20, [], [], smooth=True)
+    want = o.jafs_likelihood([])
+    assert abs(llh - want) <= llk_tol(want, row, o.JAFS, False)
+    assert float(m.group(1)) == pytest.approx(sum(inp.times[:20]) * inp.scaleTime, rel=1e-14)
+    assert "Total number of likelihood function calls is" in text
+
+
+def test_output_file_and_fractional_split(tmp_path):
+    f1, f2, fj, inp, row = write_inputs(tmp_path)
+    out = str(tmp_path / "res.mi")
+    rc, text = run_cli([f1, f2, fj, "19.5", "--cpfit", "-bs", "0", "-o", out, "--funits", str(tmp_path / "x")])
+    assert rc == 0 and os.path.exists(out)
+    lines = open(out).read().splitlines()
+    assert lines[0] == "#MiSTI2 ver 0.4" and lines[1].startswith("LK\t") and lines[2] == "ST\t20"
+    rs = [l for l in lines if l.startswith("RS\t")]
+    assert len(rs) == 33                              # numT + 1 rows after the inserted interval
+    assert len(rs[0].split("\t")) == 14 and len(rs[25].split("\t")) == 8   # Pr columns only before the split
+
+
+def test_optimised_band_and_grid(tmp_path):
+    f1, f2, fj, inp, row = write_inputs(tmp_path)
+    rc, text = run_cli([f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "-tol", "1e-3", "--funits", str(tmp_path / "x")])
+    assert rc == 0
+    m = re.search(r"optim = \[(\S+)\] \tllh = (\S+)", text)
+    assert m, text[-600:]
+    assert float(m.group(1)) >= 0 and np.isfinite(float(m.group(2)))
+    rc, text = run_cli([f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "--grid-st", "18", "22",
+                        "--grid-mi", "0", "0.001", "0.1", "4", "--all-bs", "--funits", str(tmp_path / "x")])
+    assert rc == 0
+    assert len(re.findall(r"^bs_id = ", text, flags=re.M)) == 5 * 4 * 5
+    assert "best: splitT =" in text
