@@ -34,6 +34,8 @@ def build(force=False, verbose=False, extra=()):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
            "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
     cmd += list(extra)
+    if os.environ.get("MISTI_STAMP"):
+        cmd += ["-DMISTI_STAMP=1"]
     if os.environ.get("MISTI_ABLATE"):
         cmd += ["-DMISTI_ABLATE=" + os.environ["MISTI_ABLATE"]]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]

@@ -68,6 +68,7 @@ struct misti_ctx {
     DevBuf model_f64, model_i32;        // times | lh ; run_start | run_end
     DevBuf consts;                      // llh_const per replicate
     DevBuf ws_jafs, ws_status;          // spectra / status when the caller passes NULL
+    DevBuf ws_order;                    // dispatch order (heaviest candidates first)
     DevBuf ws_lc, ws_nc;                // kernel 1 -> kernel 2: unsmoothed two-population rates, nc at the split
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool timing = false;
@@ -167,15 +168,19 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (!d_status) { HIP_TRY(c->ws_status.reserve((size_t)n_cand * sizeof(int32_t))); d_status = c->ws_status.as<int32_t>(); }
     HIP_TRY(c->ws_lc.reserve((size_t)n_cand * (c->dm.numT + 1) * 2 * sizeof(double)));
     HIP_TRY(c->ws_nc.reserve((size_t)n_cand * 2 * sizeof(double)));
+    HIP_TRY(c->ws_order.reserve((size_t)n_cand * sizeof(int32_t)));
     double* d_raw = c->ws_lc.as<double>();
     double* d_nc = c->ws_nc.as<double>();
+    int32_t* d_order = c->ws_order.as<int32_t>();
+    if (n_cand > INT32_MAX) return fail(MISTI_E_LIMIT, "n_cand exceeds 2^31-1");
+    HIP_TRY(misti::launch_order(n_cand, d_split, c->dm.numT, d_order, c->stream));
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY(misti::launch_correct(c->dm, n_cand, d_split, d_params, d_raw, d_nc, d_pr, d_status, c->stream));
+    HIP_TRY(misti::launch_correct(c->dm, n_cand, d_order, d_split, d_params, d_raw, d_nc, d_pr, d_status, c->stream));
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     if (int r = record_begin(c, 1, &a, &b)) return r;
-    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_split, d_params, d_raw, d_nc, d_lc, d_jafs, d_status, c->stream));
+    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, d_raw, d_nc, d_lc, d_jafs, d_status, c->stream));
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0) {
@@ -311,7 +316,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_lc, &c->ws_nc, &c->st_split, &c->st_params, &c->st_jsfs,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_lc, &c->ws_nc, &c->ws_order, &c->st_split, &c->st_params, &c->st_jsfs,
                     &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     for (int w = 0; w < 3; ++w)

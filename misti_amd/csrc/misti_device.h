@@ -43,9 +43,10 @@ struct DevModel {
 
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream);
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                           double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream);
-hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,

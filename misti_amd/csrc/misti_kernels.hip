@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "misti_device.h"
 
@@ -52,10 +53,11 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
-// The correction kernel packs GROUP lanes per candidate (6 of them carry the residual
-// evaluations: 3 forward-difference points x 2 genomes), i.e. 8 candidates per wavefront.
+// The correction kernel packs GROUP (8, 16, 32 or 64) lanes per candidate, 6 of which carry the
+// residual evaluations (3 forward-difference points x 2 genomes): 8 ... 1 candidates per wavefront,
+// chosen at launch from the batch size (few candidates per wave while the chip is not full).
 // Everything "uniform" is uniform within a group; cross-lane traffic never leaves a group.
-constexpr int GROUP = 8;
+template <int GROUP>
 __device__ __forceinline__ double gbcast(double v, int j) { return __shfl(v, (lane_id() & ~(GROUP - 1)) + j, 64); }
 
 __device__ __forceinline__ void lds_fence() {
@@ -97,13 +99,18 @@ struct Model {
     const DevModel* m;
     const double* par;     // [n_param] of this candidate
     int split;
+    double pv[4];          // the first parameters, cached in registers (a sweep has 1-3)
+    __device__ __forceinline__ void cache() { for (int i = 0; i < 4; ++i) pv[i] = (i < m->n_param) ? par[i] : 0.0; }
+    __device__ __forceinline__ double param(int i) const {
+        return i == 0 ? pv[0] : i == 1 ? pv[1] : i == 2 ? pv[2] : i == 3 ? pv[3] : par[i];
+    }
     __device__ __forceinline__ void mig(int t, double& mu0, double& mu1) const {
         mu0 = 0.0; mu1 = 0.0;
         for (int b = 0; b < m->n_band; ++b) {
             const misti_band_t& B = m->bands[b];
             int end = B.end < 0 ? split : B.end;
             if (t >= B.start && t < end) {
-                double v = B.param >= 0 ? par[B.param] : B.value;
+                double v = B.param >= 0 ? param(B.param) : B.value;
                 if (B.pop == 0) mu0 = v; else mu1 = v;
             }
         }
@@ -113,7 +120,7 @@ struct Model {
         for (int b = 0; b < m->n_pulse; ++b) {
             const misti_pulse_t& P = m->pulses[b];
             if (t == P.time) {
-                double v = P.param >= 0 ? par[P.param] : P.value;
+                double v = P.param >= 0 ? param(P.param) : P.value;
                 if (P.pop == 0) pu0 = v; else pu1 = v;
             }
         }
@@ -130,23 +137,19 @@ struct Model {
 // count is wave-uniform (bound from the largest q in the wave).
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
 struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0; };
-__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], bool active, Diag& dg) {
-    bool ok = isfinite(l0) && isfinite(l1);
-    if (!active || !ok) { l0 = 0.0; l1 = 0.0; }
+// q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
+// base point and both forward-difference points).  M = N - q I with N >= 0.  When a state is
+// numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway rate
+// with one-directional migration) the forward-difference lanes then perform bit-identical
+// arithmetic on the remaining components, so the Jacobian column is exactly zero - as it is in
+// the reference, whose solver leaves that rate untouched.
+__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], double q, double neg, bool ok, Diag& dg) {
+    if (!ok) { l0 = 0.0; l1 = 0.0; }
     double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1;
-    // M = N - q I with N >= 0.  q is the SAME for every lane of the wave: when a state is
-    // numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway
-    // rate with one-directional migration) the forward-difference lanes then perform
-    // bit-identical arithmetic on the remaining components, so the Jacobian column is
-    // exactly zero - as it is in the reference, whose solver leaves that rate untouched.
-    // ("wave" = the GROUP lanes of one candidate.)
-    double q = fmax(fmax(d0, d1), fmax(d2, 0.0));
-    double neg = fmax(0.0, fmax(-l0, -l1));
-    for (int o = GROUP / 2; o > 0; o >>= 1) { q = fmax(q, __shfl_xor(q, o, 64)); neg = fmax(neg, __shfl_xor(neg, o, 64)); }
     double nbmax = q + neg;                                  // >= ||N||_1 (column sums q - l0, q - l1, q)
     if (!(nbmax < 1e300)) {                                  // overflowing iterate: report non-finite (TRF shrinks the step)
         dg.guard = true;
-        if (active) { v[0] = v[1] = v[2] = NAN; }
+        v[0] = v[1] = v[2] = NAN;
         return;
     }
     if (nbmax > 6.0) {
@@ -175,7 +178,7 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         double w1 = (E[1][0] * v[0] + E[1][1] * v[1]) + E[1][2] * v[2];
         double w2 = (E[2][0] * v[0] + E[2][1] * v[1]) + E[2][2] * v[2];
         v[0] = w0; v[1] = w1; v[2] = w2;
-        if (active && !ok) { v[0] = v[1] = v[2] = NAN; }
+        if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
     const int nsub = 1;
@@ -201,7 +204,7 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         }
         v[0] = a0; v[1] = a1; v[2] = a2;
     }
-    if (active && !ok) { v[0] = v[1] = v[2] = NAN; }
+    if (!ok) { v[0] = v[1] = v[2] = NAN; }
 }
 
 // 3x3 inverse times vector (for the default-fit residual, CorrectLambda.py:99-107)
@@ -566,132 +569,93 @@ __device__ __forceinline__ double ect_one_pop(double lam, double T) {
 __device__ __forceinline__ double ect_noncond(double lam, double T) { return (1.0 - exp(-lam * T) * (1.0 + lam * T)) / lam; }
 
 // Residuals of the migrating two-population interval, evaluated for the base
-// point and both forward-difference points in one wave pass.
-// lane (within the candidate's group) = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
+// point and both forward-difference points in one pass of the candidate's lane group.
+// lane (within the group) = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
 struct PairProblem {
     double mu0, mu1;       // stretched to unit interval (CorrectLambda.py:293-298)
-    double lh0, lh1;       // stretched
     double P[2][3];        // pair-state vectors at the start of the interval
-    bool cpfit;
+    double s[2];           // their sums
+    double tgt[2];         // cpfit: exp(-lh_k) * s_k (:141); default fit: one-population expected coalescence time (:74-77)
 };
-struct PairEval {
-    double f[2];           // residual at the base point
-    double J[2][2];        // forward-difference Jacobian
-    double v[2][3];        // exp(M) P[k] at the base point
-    bool finite;
-};
-template <bool CPFIT>
-__device__ __forceinline__ PairEval pair_eval(const PairProblem& pb, double x0, double x1, int lane, Diag& dg) {
-    double h0 = fd_step(x0), h1 = fd_step(x1);
-    double xa = x0 + h0, xb = x1 + h1;
-    double dx0 = xa - x0, dx1 = xb - x1;            // recomputed as exactly representable (_numdiff.py)
-    int e = lane >> 1, k = lane & 1;
-    bool active = lane < 6;
-    double l0 = (e == 1) ? xa : x0;
-    double l1 = (e == 2) ? xb : x1;
-    double v[3];
-    double s = 0.0;
-    for (int i = 0; i < 3; ++i) { v[i] = k ? pb.P[1][i] : pb.P[0][i]; }
-    s = (v[0] + v[1]) + v[2];
+
+template <bool CPFIT, int GROUP>
+__device__ __forceinline__ void pair_batch(const PairProblem& pb, const double xe[2], int sub, Diag& dg,
+                                           double f[2], double J[2][2], double w[3], bool& finite) {
+    const double x0 = xe[0], x1 = xe[1];
+    const double h0 = fd_step(x0), h1 = fd_step(x1);
+    const double xa = x0 + h0, xb = x1 + h1;
+    const double dx0 = xa - x0, dx1 = xb - x1;      // recomputed as exactly representable (_numdiff.py)
+    const int e = sub >> 1, k = sub & 1;
+    const double l0 = (e == 1) ? xa : x0;
+    const double l1 = (e == 2) ? xb : x1;
+    const bool ok = isfinite(x0) && isfinite(x1);
+    // group-uniform uniformisation rate: the largest over the three evaluation points
+    const double m0 = fmax(x0, xa), m1 = fmax(x1, xb);
+    const double q = fmax(fmax(2.0 * pb.mu0 + m0, 2.0 * pb.mu1 + m1), fmax(pb.mu0 + pb.mu1, 0.0));
+    const double neg = fmax(0.0, fmax(-fmin(x0, xa), -fmin(x1, xb)));
+    const double sk = k ? pb.s[1] : pb.s[0];
     double res;
     if (CPFIT) {
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
-        double w[3] = {v[0], v[1], v[2]};
-#if !defined(MISTI_ABLATE) || MISTI_ABLATE != 2
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, dg);
+        for (int i = 0; i < 3; ++i) w[i] = k ? pb.P[1][i] : pb.P[0][i];
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg);
+#if defined(MISTI_ABLATE) && MISTI_ABLATE == 11
+        { double w2[3] = {w[0] * 0.5, w[1] * 0.25, w[2] * 0.125}; Diag d2; pair_expv(l0, l1, pb.mu0, pb.mu1, w2, q, neg, ok, d2);
+          asm volatile("" :: "v"(w2[0]), "v"(w2[1]), "v"(w2[2])); }
 #endif
-        double nch = exp(-(k ? pb.lh1 : pb.lh0)) * s;
-        res = ((w[0] + w[1]) + w[2]) - nch;
-        v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+        res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
-        double pn[3] = {v[0] / s, v[1] / s, v[2] / s};
-        double w[3] = {pn[0], pn[1], pn[2]};
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, active, dg);
+        double pn[3];
+        for (int i = 0; i < 3; ++i) { pn[i] = (k ? pb.P[1][i] : pb.P[0][i]) / sk; w[i] = pn[i]; }
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg);
         double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
-        double d[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
+        double dd[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
         double y[3], vec1[3], vec2[3];
-        solve3(M, d, y);
+        solve3(M, dd, y);
         solve3(M, y, vec1);
         double pnc = (w[0] + w[1]) + w[2];
         solve3(M, w, vec2);                         // T = 1 after the stretch
         double ect = (l0 * (vec2[0] - vec1[0]) + l1 * (vec2[1] - vec1[1])) / (1.0 - pnc);
-        double lam = k ? pb.lh1 : pb.lh0;           // ExpectedCoalTimeOnePopTmp :74-77 with T = 1
-        double pn1 = exp(-lam);
-        double tc1 = 1.0 / lam - 1.0 / (1.0 / pn1 - 1.0);
-        res = ect - tc1;
+        res = ect - (k ? pb.tgt[1] : pb.tgt[0]);
         // the state vector handed on is exp(M) applied to the unnormalised vector
-        v[0] = w[0] * s; v[1] = w[1] * s; v[2] = w[2] * s;
+        w[0] *= sk; w[1] *= sk; w[2] *= sk;
     }
-    PairEval o;
-    double fb0 = gbcast(res, 0), fb1 = gbcast(res, 1);
-    double fa0 = gbcast(res, 2), fa1 = gbcast(res, 3);
-    double fc0 = gbcast(res, 4), fc1 = gbcast(res, 5);
-    o.f[0] = fb0; o.f[1] = fb1;
-    o.J[0][0] = (fa0 - fb0) / dx0; o.J[1][0] = (fa1 - fb1) / dx0;
-    o.J[0][1] = (fc0 - fb0) / dx1; o.J[1][1] = (fc1 - fb1) / dx1;
-    for (int i = 0; i < 3; ++i) { o.v[0][i] = gbcast(v[i], 0); o.v[1][i] = gbcast(v[i], 1); }
-    o.finite = isfinite(fb0) && isfinite(fb1);
-    return o;
+    const double fb0 = gbcast<GROUP>(res, 0), fb1 = gbcast<GROUP>(res, 1);
+    const double fa0 = gbcast<GROUP>(res, 2), fa1 = gbcast<GROUP>(res, 3);
+    const double fc0 = gbcast<GROUP>(res, 4), fc1 = gbcast<GROUP>(res, 5);
+#if defined(MISTI_ABLATE) && MISTI_ABLATE == 12
+    { double z0 = gbcast<GROUP>(res * 0.5, 0), z1 = gbcast<GROUP>(res * 0.5, 1), z2 = gbcast<GROUP>(res * 0.5, 2), z3 = gbcast<GROUP>(res * 0.5, 3), z4 = gbcast<GROUP>(res * 0.5, 4), z5 = gbcast<GROUP>(res * 0.5, 5);
+      asm volatile("" :: "v"(z0), "v"(z1), "v"(z2), "v"(z3), "v"(z4), "v"(z5)); }
+#endif
+    const double r0 = 1.0 / dx0, r1 = 1.0 / dx1;
+    f[0] = fb0; f[1] = fb1;
+    J[0][0] = (fa0 - fb0) * r0; J[1][0] = (fa1 - fb1) * r0;
+    J[0][1] = (fc0 - fb0) * r1; J[1][1] = (fc1 - fb1) * r1;
+    finite = isfinite(fb0) && isfinite(fb1);
 }
 
-// trf_no_bounds (trf.py:401-560) on the residual above.  Returns x and the
-// propagated pair vectors exp(M(x)) P[k] (CorrectLambda.py:313-317).
-template <bool CPFIT>
-__device__ __forceinline__ void trf2_unbounded(const PairProblem& pb, double x[2], double vout[2][3], int lane, Diag& dg) {
-    PairEval ev = pair_eval<CPFIT>(pb, x[0], x[1], lane, dg);
-    double f[2] = {ev.f[0], ev.f[1]};
-    double J[2][2] = {{ev.J[0][0], ev.J[0][1]}, {ev.J[1][0], ev.J[1][1]}};
-    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) vout[k][i] = ev.v[k][i];
-    int nfev = 1;
-    const int max_nfev = 200;
-    double cost = 0.5 * (f[0] * f[0] + f[1] * f[1]);
-    struct Tally { Diag& d; int& n; __device__ ~Tally() { d.evals += n; d.max_nfev = n > d.max_nfev ? n : d.max_nfev; } } tally{dg, nfev};
-#if defined(MISTI_ABLATE) && MISTI_ABLATE == 1
-    return;
-#endif
-    double g[2] = {J[0][0] * f[0] + J[1][0] * f[1], J[0][1] * f[0] + J[1][1] * f[1]};
-    double Delta = sqrt(x[0] * x[0] + x[1] * x[1]);
-    if (Delta == 0) Delta = 1.0;
-    double alpha = 0.0;
-    int term = 0;
-    for (;;) {
-        double g_norm = fmax(fabs(g[0]), fabs(g[1]));
-        if (g_norm < LSQ_GTOL) term = 1;
-        if (term != 0 || nfev >= max_nfev) break;
-        if (!(g_norm < INFINITY)) break;                       // NaN residuals: give up (result fails downstream)
-        Svd2 sv = svd_mx2<2>(J, f);
-        double actual = -1.0;
-        double xn[2] = {x[0], x[1]}, fn[2] = {f[0], f[1]}, cost_new = cost;
-        PairEval en = ev;
-        while (actual <= 0 && nfev < max_nfev) {
-            double p[2];
-            solve_tr(sv, 2, Delta, alpha, p);
-            double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
-            double predicted = -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
-            xn[0] = x[0] + p[0]; xn[1] = x[1] + p[1];
-            en = pair_eval<CPFIT>(pb, xn[0], xn[1], lane, dg);
-            ++nfev;
-            double step_norm = sqrt(p[0] * p[0] + p[1] * p[1]);
-            if (!en.finite) { Delta = 0.25 * step_norm; continue; }
-            fn[0] = en.f[0]; fn[1] = en.f[1];
-            cost_new = 0.5 * (fn[0] * fn[0] + fn[1] * fn[1]);
-            actual = cost - cost_new;
-            double ratio;
-            double Delta_new = update_radius(Delta, actual, predicted, step_norm, step_norm > 0.95 * Delta, ratio);
-            term = check_term(actual, cost, step_norm, sqrt(x[0] * x[0] + x[1] * x[1]), ratio);
-            if (term != 0) break;
-            alpha *= Delta / Delta_new;
-            Delta = Delta_new;
-        }
-        if (actual > 0) {
-            x[0] = xn[0]; x[1] = xn[1]; f[0] = fn[0]; f[1] = fn[1]; cost = cost_new;
-            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = en.J[r][c];
-            for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) vout[k][i] = en.v[k][i];
-            g[0] = J[0][0] * f[0] + J[1][0] * f[1];
-            g[1] = J[0][1] * f[0] + J[1][1] * f[1];
-        }
+// Next trial step of trf_no_bounds (trf.py:469-486): Gauss-Newton step when the Jacobian has
+// full rank and the step lies in the trust region (solve_lsq_trust_region, common.py:116-125),
+// otherwise the regularised step from the SVD.  Returns the predicted reduction.
+__device__ __forceinline__ double next_step(const double J[2][2], const double f[2], const double g[2], double Delta, double& alpha,
+                                            Svd2& sv, bool& have_sv, double p[2]) {
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double F = (J[0][0] * J[0][0] + J[0][1] * J[0][1]) + (J[1][0] * J[1][0] + J[1][1] * J[1][1]);
+    bool done = false;
+    // s_max^2 <= F <= 2 s_max^2 and s_min = |det| / s_max: full rank (s_min > 2 eps s_max) is certain if |det| > 2 eps F
+    if (fabs(det) > 2.0 * LSQ_EPS * 2.0 * F) {
+        const double rd = 1.0 / det;
+        const double p0 = -(J[1][1] * f[0] - J[0][1] * f[1]) * rd;
+        const double p1 = -(J[0][0] * f[1] - J[1][0] * f[0]) * rd;
+        if (p0 * p0 + p1 * p1 <= Delta * Delta) { p[0] = p0; p[1] = p1; alpha = 0.0; done = true; }
     }
+    if (!done) {
+        if (!have_sv) { sv = svd_mx2<2>(J, f); have_sv = true; }
+        solve_tr(sv, 2, Delta, alpha, p);
+    }
+    const double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
+    return -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
 }
 
 // ------------------------------------------------ two-population correction --
@@ -710,67 +674,6 @@ __device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu
         ps.p[k][b] = pa * (r * r) + pb + pc * r;
         ps.p[k][2] = pa * 2 * omr * r + pc * omr;
     }
-}
-
-// One interval of SolveLambdaSystem (CorrectLambda.py:266-317); lc < 0 signals failure.
-template <bool CPFIT>
-__device__ __forceinline__ void correct_interval(const DevModel& m, double lh0, double lh1, double T, double mu0, double mu1,
-                                                 PairState& ps, double lc[2], int lane, Diag& dg) {
-    constexpr bool cpfit = CPFIT;
-    double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
-    double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
-    double mix = 0.0;
-    for (int i = 0; i < 3; ++i) { double d = ps.p[0][i] / s0 - ps.p[1][i] / s1; mix += d * d; }
-    mix = sqrt(mix);
-    if (mix < m.mixture_th) { lc[0] = lc[1] = -1.0; return; }                       // :271-272
-    if (mu0 + mu1 < 1e-10) {
-        if (cpfit) {
-            // SolveNoMigration1 :213-235
-            double A1 = ps.p[0][0] / s0, A2 = ps.p[0][1] / s0, A3 = ps.p[1][0] / s1, A4 = ps.p[1][1] / s1;
-            double C1 = ps.p[0][2] / s0, C2 = ps.p[1][2] / s1;
-            double D = A1 * A4 - A2 * A3;
-            double B1 = A4 / D, B2 = -A2 / D, B3 = -A3 / D, B4 = A1 / D;
-            double X1 = exp(-lh0 * T) - C1, X2 = exp(-lh1 * T) - C2;
-            double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
-            if (y0 > 0 && y1 > 0) { lc[0] = -log(y0) / T; lc[1] = -log(y1) / T; }
-            else { lc[0] = lc[1] = -1.0; }
-            double e0 = exp(-lc[0] * T), e1 = exp(-lc[1] * T);
-            for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
-            return;
-        }
-        // SolveNoMigration :253-264: bounded 2-D fit of the conditional expected coalescence time
-        double pr[2][3];
-        for (int i = 0; i < 3; ++i) { pr[0][i] = ps.p[0][i] / s0; pr[1][i] = ps.p[1][i] / s1; }
-        double tgt0 = ect_one_pop(lh0, T), tgt1 = ect_one_pop(lh1, T);
-        auto resid = [&](const double l[2], double f[2]) {          // LambdaSystemNoMigration :237-251
-            double e0 = exp(-l[0] * T), e1 = exp(-l[1] * T);
-            double n0 = ect_noncond(l[0], T), n1 = ect_noncond(l[1], T);
-            for (int k = 0; k < 2; ++k) {
-                double pnc = pr[k][0] * e0 + pr[k][1] * e1 + pr[k][2];
-                double ct = (pr[k][0] * n0 + pr[k][1] * n1) / (1.0 - pnc);
-                f[k] = ct - (k ? tgt1 : tgt0);
-            }
-        };
-        double x[2] = {lh0, lh1};
-        trf_bounded<2>(resid, x, 0.01 * fmin(lh0, lh1));
-        lc[0] = x[0]; lc[1] = x[1];
-        double e0 = exp(-lc[0] * T), e1 = exp(-lc[1] * T);
-        for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
-        return;
-    }
-    double n0 = 0, n1 = 0, nd = 0;                                                   // :278-290
-    for (int i = 0; i < 3; ++i) { n0 += ps.p[0][i] * ps.p[0][i]; n1 += ps.p[1][i] * ps.p[1][i]; double d = ps.p[0][i] - ps.p[1][i]; nd += d * d; }
-    n0 = sqrt(n0); n1 = sqrt(n1); nd = sqrt(nd);
-    if (nd < 0.02 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; }
-    PairProblem pb;
-    pb.mu0 = mu0 * T; pb.mu1 = mu1 * T; pb.lh0 = lh0 * T; pb.lh1 = lh1 * T;         // stretch :293-298
-    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
-    pb.cpfit = cpfit;
-    double x[2] = {pb.lh0, pb.lh1};
-    double v[2][3];
-    trf2_unbounded<CPFIT>(pb, x, v, lane, dg);
-    lc[0] = x[0] / T; lc[1] = x[1] / T;                                              // :312
-    for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) ps.p[k][i] = v[k][i];
 }
 
 // ----------------------------------------------------------- the kernels ----
@@ -794,58 +697,232 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
 }
 
 // Kernel 1: lambda correction of the two-population intervals (CorrectLambdas loop t < splitT,
-// MigrationInference.py:307-354).  GROUP lanes per candidate, 8 candidates per wavefront, no LDS.
+// MigrationInference.py:307-354; SolveLambdaSystem, CorrectLambda.py:266-317).
+// GROUP lanes per candidate, 8 candidates per wavefront, no LDS.  Each candidate runs its own
+// resumable state machine: one pass of the loop = one residual batch (trial point + its
+// forward-difference points) + the trust-region bookkeeping of trf_no_bounds (trf.py:401-560),
+// so the candidates of a wavefront never wait for each other interval by interval.
 // Writes the unsmoothed corrected rates of the two-population intervals lc_raw[cand][numT+1][2],
 // the non-coalescence sums nc[cand][2] at the split (:353-354), the pair-state trace, the status.
-template <bool CPFIT>
+template <bool CPFIT, int GROUP>
 __global__ __launch_bounds__(64)
-void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
+void correct_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                     double* __restrict__ lc_raw, double* __restrict__ nc_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
     const int lane = lane_id();
     const int sub = lane & (GROUP - 1);
-    const int64_t cand = ((int64_t)blockIdx.x * (64 / GROUP)) + (lane / GROUP);
-    if (cand >= n_cand) return;
+    const int64_t slot = ((int64_t)blockIdx.x * (64 / GROUP)) + (lane / GROUP);
+    // the shared grid (interval lengths, PSMC rates) staged in LDS: every pass of the state
+    // machine of some candidate reads it, and an L2 round trip per read dominated the kernel
+    extern __shared__ double lds[];
+    {
+        const int nt = m.numT - 1, nl = 2 * m.numT;
+        for (int i = lane; i < nt; i += 64) lds[i] = m.times[i];
+        for (int i = lane; i < nl; i += 64) lds[nt + i] = m.lh[i];
+    }
+    __syncthreads();
+    const bool in_range = slot < n_cand;
+    const int64_t cand = order[in_range ? slot : n_cand - 1];      // heaviest (largest split) first
+    const int64_t cand_c = cand;
     const int lc_rows = m.numT + 1;
-    const double* par = params ? params + cand * m.n_param : nullptr;
+    const double* par = params ? params + cand_c * m.n_param : nullptr;
     Grid G;
-    int status = setup_candidate(m, split_time[cand], par, G);
-    Model mod{&m, par, G.split};
+    int status = setup_candidate(m, split_time[cand_c], par, G);
+    G.times = lds; G.lh = lds + (m.numT - 1);
+    if (!in_range) return;
+    Model mod{&m, par, G.split, {0, 0, 0, 0}};
+    mod.cache();
     const bool correct = !(m.flags & MISTI_TRUE_EPS);
     double* pr_c = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
     double* lc_c = lc_raw + cand * (int64_t)lc_rows * 2;
+    const int max_nfev = 200;                    // 100 * n (least_squares.py)
 
-    Diag dg;                // overflow guard + work counters
+    Diag dg;
     PairState ps;
     ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
     ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
-    if (status == MISTI_OK) {
-        if (pr_c && sub == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
-        for (int t = 0; t < G.split; ++t) {
-            double pu0, pu1, mu0, mu1;
-            mod.pulse(t, pu0, pu1);
-            mod.mig(t, mu0, mu1);
-            pulse_pairs(ps, pu0, pu1);
-            double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
-            double lc[2] = {lh0, lh1};
-            if (correct) {
-                correct_interval<CPFIT>(m, lh0, lh1, G.T(t), mu0, mu1, ps, lc, sub, dg);
-                if (!(lc[0] > 0) || !(lc[1] > 0)) {                                    // :346-348 (NaN fails too)
-                    status = (isnan(lc[0]) || isnan(lc[1])) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
-                    if (sub == 0) { lc_c[2 * t] = lc[0]; lc_c[2 * t + 1] = lc[1]; }
-                    break;
+    if (status == MISTI_OK && pr_c && sub == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
+
+    // solver state of the interval in progress
+    PairProblem pb;
+    double T = 0.0;
+    double x[2] = {0, 0}, f[2] = {0, 0}, J[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0}, xe[2] = {0, 0}, p[2] = {0, 0}, vk[3] = {0, 0, 0};
+    double cost = 0.0, Delta = 0.0, alpha = 0.0, predicted = 0.0;
+    int nfev = 0, t = 0;
+    bool first = false, in_solve = false, have_sv = false;
+    Svd2 sv;
+
+    auto finish_interval = [&](double lc0, double lc1) -> bool {       // :345-350; false = correction failed
+        if (sub == 0) { lc_c[2 * t] = lc0; lc_c[2 * t + 1] = lc1; }
+        if (!(lc0 > 0) || !(lc1 > 0)) {
+            status = (isnan(lc0) || isnan(lc1)) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
+            return false;
+        }
+        if (pr_c && sub == 0) {
+            double* r = pr_c + 6 * (t + 1);
+            r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
+        }
+        ++t;
+        return true;
+    };
+
+#ifdef MISTI_STAMP
+    long long c_adv = 0, c_batch = 0, c_book = 0, c_t0 = 0;
+#define STAMP(acc) { long long now_ = clock64(); acc += now_ - c_t0; c_t0 = now_; }
+#else
+#define STAMP(acc)
+#endif
+    bool active = status == MISTI_OK;
+#ifdef MISTI_STAMP
+    c_t0 = clock64();
+#endif
+    while (active) {
+        if (!in_solve) {
+            // ---- advance over intervals until one needs the iterative solver ----------
+            while (t < G.split) {
+                double pu0, pu1, mu0, mu1;
+                mod.pulse(t, pu0, pu1);
+                mod.mig(t, mu0, mu1);
+                pulse_pairs(ps, pu0, pu1);                                              // :315-323
+                double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
+                if (!correct) { if (!finish_interval(lh0, lh1)) break; continue; }       // :325-326
+                T = G.T(t);
+                const double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
+                const double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
+                if (m.mixture_th > 0.0) {                                               // CorrectLambda.py:267-272 (threshold 0 never fires)
+                    double mix = 0.0;
+                    for (int i = 0; i < 3; ++i) { double d = ps.p[0][i] / s0 - ps.p[1][i] / s1; mix += d * d; }
+                    if (sqrt(mix) < m.mixture_th) { finish_interval(-1.0, -1.0); break; }
                 }
+                if (mu0 + mu1 < 1e-10) {
+                    double lc0, lc1;
+                    if (CPFIT) {
+                        // SolveNoMigration1 :213-235
+                        double A1 = ps.p[0][0] / s0, A2 = ps.p[0][1] / s0, A3 = ps.p[1][0] / s1, A4 = ps.p[1][1] / s1;
+                        double C1 = ps.p[0][2] / s0, C2 = ps.p[1][2] / s1;
+                        double D = A1 * A4 - A2 * A3;
+                        double B1 = A4 / D, B2 = -A2 / D, B3 = -A3 / D, B4 = A1 / D;
+                        double X1 = exp(-lh0 * T) - C1, X2 = exp(-lh1 * T) - C2;
+                        double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
+                        if (y0 > 0 && y1 > 0) { lc0 = -log(y0) / T; lc1 = -log(y1) / T; }
+                        else { lc0 = lc1 = -1.0; }
+                    } else {
+                        // SolveNoMigration :253-264: bounded 2-D fit of the conditional expected coalescence time
+                        double pr[2][3];
+                        for (int i = 0; i < 3; ++i) { pr[0][i] = ps.p[0][i] / s0; pr[1][i] = ps.p[1][i] / s1; }
+                        double tgt0 = ect_one_pop(lh0, T), tgt1 = ect_one_pop(lh1, T);
+                        auto resid = [&](const double l[2], double ff[2]) {          // LambdaSystemNoMigration :237-251
+                            double e0 = exp(-l[0] * T), e1 = exp(-l[1] * T);
+                            double n0 = ect_noncond(l[0], T), n1 = ect_noncond(l[1], T);
+                            for (int k = 0; k < 2; ++k) {
+                                double pnc = pr[k][0] * e0 + pr[k][1] * e1 + pr[k][2];
+                                double ct = (pr[k][0] * n0 + pr[k][1] * n1) / (1.0 - pnc);
+                                ff[k] = ct - (k ? tgt1 : tgt0);
+                            }
+                        };
+                        double xx[2] = {lh0, lh1};
+                        trf_bounded<2>(resid, xx, 0.01 * fmin(lh0, lh1));
+                        lc0 = xx[0]; lc1 = xx[1];
+                    }
+                    double e0 = exp(-lc0 * T), e1 = exp(-lc1 * T);
+                    for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
+                    if (!finish_interval(lc0, lc1)) break;
+                    continue;
+                }
+                // migrating interval: set the 2x2 problem up (:278-305) and leave the advance loop
+                double n0 = 0, n1 = 0, nd = 0;
+                for (int i = 0; i < 3; ++i) { n0 += ps.p[0][i] * ps.p[0][i]; n1 += ps.p[1][i] * ps.p[1][i]; double d = ps.p[0][i] - ps.p[1][i]; nd += d * d; }
+                if (nd < 0.0004 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; }   // normD < 0.02 min(norms), squared
+                pb.mu0 = mu0 * T; pb.mu1 = mu1 * T;                                      // stretch :293-298
+                const double lhs0 = lh0 * T, lhs1 = lh1 * T;
+                for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
+                pb.s[0] = s0; pb.s[1] = s1;
+                if (CPFIT) { pb.tgt[0] = exp(-lhs0) * s0; pb.tgt[1] = exp(-lhs1) * s1; }
+                else {
+                    double pa = exp(-lhs0), pbb = exp(-lhs1);                            // ExpectedCoalTimeOnePopTmp, T = 1
+                    pb.tgt[0] = 1.0 / lhs0 - 1.0 / (1.0 / pa - 1.0);
+                    pb.tgt[1] = 1.0 / lhs1 - 1.0 / (1.0 / pbb - 1.0);
+                }
+                xe[0] = lhs0; xe[1] = lhs1;
+                first = true; in_solve = true; have_sv = false;
+                break;
             }
-            if (sub == 0) { lc_c[2 * t] = lc[0]; lc_c[2 * t + 1] = lc[1]; }
-            if (pr_c && sub == 0) {
-                double* r = pr_c + 6 * (t + 1);
-                r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
+            if (!in_solve) { active = false; break; }              // reached the split, or failed
+        }
+        STAMP(c_adv)
+        // ---- one residual batch at xe -------------------------------------------------
+        double fn[2], Jn[2][2], w[3];
+        bool finite;
+        pair_batch<CPFIT, GROUP>(pb, xe, sub, dg, fn, Jn, w, finite);
+        dg.evals += 1;
+        STAMP(c_batch)
+        // ---- trust-region bookkeeping (trf_no_bounds) -----------------------------------
+        bool accept = false, done = false;
+        int term = 0;
+        double cost_new = 0.5 * (fn[0] * fn[0] + fn[1] * fn[1]);
+        if (first) {
+            first = false;
+            nfev = 1;
+            if (!finite) { status = MISTI_NUMERIC; active = false; break; }   // SciPy raises on a non-finite start
+            Delta = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+            if (Delta == 0) Delta = 1.0;
+            alpha = 0.0;
+            accept = true;
+        } else {
+            ++nfev;
+            const double sn2 = p[0] * p[0] + p[1] * p[1];
+            if (!finite) { Delta = 0.25 * sqrt(sn2); }
+            else {
+                const double actual = cost - cost_new;
+                double ratio;
+                if (predicted > 0) ratio = actual / predicted;
+                else if (predicted == 0 && actual == 0) ratio = 1.0;
+                else ratio = 0.0;
+                double Delta_new = Delta;                                    // update_tr_radius, common.py:222-245
+                if (ratio < 0.25) Delta_new = 0.25 * sqrt(sn2);
+                else if (ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) Delta_new = 2.0 * Delta;
+                const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;  // check_termination, common.py:705-717
+                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt(x[0] * x[0] + x[1] * x[1]));
+                const bool x_ok = sn2 < lim * lim;
+                term = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0;
+                if (term == 0) { if (alpha != 0.0) alpha *= Delta / Delta_new; Delta = Delta_new; }
+                accept = actual > 0;
             }
         }
+        if (accept) {
+            x[0] = xe[0]; x[1] = xe[1]; f[0] = fn[0]; f[1] = fn[1]; cost = cost_new;
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = Jn[r][c];
+            vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2];
+            g[0] = J[0][0] * f[0] + J[1][0] * f[1];
+            g[1] = J[0][1] * f[0] + J[1][1] * f[1];
+            have_sv = false;
+        }
+        if (term != 0) done = true;
+        else if (accept) {
+            const double g_norm = fmax(fabs(g[0]), fabs(g[1]));
+            if (g_norm < LSQ_GTOL || nfev >= max_nfev || !(g_norm < INFINITY)) done = true;
+        } else if (nfev >= max_nfev) done = true;
+        if (!done) {
+#if defined(MISTI_ABLATE) && MISTI_ABLATE == 13
+            { double a2 = alpha, p2[2]; Svd2 s2; bool h2 = false; double f2[2] = {f[0] * 0.5, f[1] * 0.5};
+              double pr2 = next_step(J, f2, g, Delta, a2, s2, h2, p2); asm volatile("" :: "v"(pr2), "v"(p2[0]), "v"(p2[1])); }
+#endif
+            predicted = next_step(J, f, g, Delta, alpha, sv, have_sv, p);
+            xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
+        } else {
+            dg.max_nfev = nfev > dg.max_nfev ? nfev : dg.max_nfev;
+            for (int i = 0; i < 3; ++i) { ps.p[0][i] = gbcast<GROUP>(vk[i], 0); ps.p[1][i] = gbcast<GROUP>(vk[i], 1); }   // :313-317
+            in_solve = false;
+            if (!finish_interval(x[0] / T, x[1] / T)) { active = false; break; }                              // :312, :346-348
+        }
+        STAMP(c_book)
     }
     if (status == MISTI_OK && dg.guard) status = MISTI_NUMERIC;
     if (pr_c && sub == 0) {                       // last row of the trace buffer: work counters of this candidate
         double* r = pr_c + 6 * (m.numT + 1);
         r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = 0.0;
+#ifdef MISTI_STAMP
+        r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
+#endif
     }
     if (sub == 0) {
         status_out[cand] = status;
@@ -860,14 +937,15 @@ void correct_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 // LDS per wave (doubles): xbuf[128] (re | im) | lc[2*(numT0+1)]
 template <bool CPFIT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
-void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params,
+void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      const double* __restrict__ lc_raw, const double* __restrict__ nc_in, double* __restrict__ lc_out,
                      double* __restrict__ jafs_out, int32_t* __restrict__ status_io) {
     extern __shared__ double lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
-    const int64_t cand = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (cand >= n_cand) return;
+    const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (slot >= n_cand) return;
+    const int64_t cand = order[slot];
     const int lc_rows = m.numT + 1;
     double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
     double* lcb = xbuf + 128;
@@ -875,7 +953,8 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ spli
     const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
     (void)setup_candidate(m, split_time[cand], par, G);
-    Model mod{&m, par, G.split};
+    Model mod{&m, par, G.split, {0, 0, 0, 0}};
+    mod.cache();
     double* lc_o = lc_out ? lc_out + cand * (int64_t)lc_rows * 2 : nullptr;
     if (status != MISTI_OK) {
         if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
@@ -1142,6 +1221,30 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const double* __restrict__ spli
     }
 }
 
+// Dispatch order: candidates sorted by descending split index (counting sort, one workgroup).
+// Work per candidate grows with the number of two-population intervals, and the workgroup
+// dispatcher hands blocks out in index order, so the longest chains start first and the
+// short ones fill in behind them.  The order never affects a candidate's result.
+__global__ __launch_bounds__(256)
+void order_kernel(int64_t n_cand, const double* __restrict__ split_time, int numT, int32_t* __restrict__ order) {
+    __shared__ int hist[MISTI_MAX_NUMT + 4];
+    const int nb = numT + 3;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
+    for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
+}
+
+hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, stream, n_cand, split, numT, order);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------- replicate epilogue --
 // llh_const of SetJAFS (MigrationInference.py:217-227): one thread per replicate.
 __global__ void llh_const_kernel(int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
@@ -1213,28 +1316,52 @@ hipError_t upload_tables(const DevTables& t) {
 
 size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
 
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const double* split, const double* params,
-                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
-    if (n_cand <= 0) return hipSuccess;
+template <bool CPFIT, int GROUP>
+static void launch_correct_t(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
+                             double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
     const int per_wave = 64 / GROUP;
     dim3 grid((unsigned)((n_cand + per_wave - 1) / per_wave));
-    if (m.flags & MISTI_CPFIT)
-        hipLaunchKernelGGL(correct_kernel<true>, grid, dim3(64), 0, stream, m, n_cand, split, params, lc_raw, nc, pr, status);
-    else
-        hipLaunchKernelGGL(correct_kernel<false>, grid, dim3(64), 0, stream, m, n_cand, split, params, lc_raw, nc, pr, status);
+    const size_t lds = (size_t)(3 * m.numT - 1) * sizeof(double);
+    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, order, split, params, lc_raw, nc, pr, status);
+}
+
+// Candidates per wavefront: 8 when the batch fills the chip several times over, fewer for small
+// batches (less divergence between the candidates of a wave, more wavefronts to overlap latency).
+int correct_cands_per_wave(int64_t n_cand) {
+    static const int forced = [] { const char* e = getenv("MISTI_CANDS_PER_WAVE"); return e ? atoi(e) : 0; }();
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    int cpw = 8;
+    while (cpw > 1 && n_cand / cpw < 2048) cpw /= 2;
+    return cpw;
+}
+
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
+                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    const bool cp = m.flags & MISTI_CPFIT;
+    switch (correct_cands_per_wave(n_cand)) {
+        case 8: cp ? launch_correct_t<true, 8>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
+                   : launch_correct_t<false, 8>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
+        case 4: cp ? launch_correct_t<true, 16>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
+                   : launch_correct_t<false, 16>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
+        case 2: cp ? launch_correct_t<true, 32>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
+                   : launch_correct_t<false, 32>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
+        default: cp ? launch_correct_t<true, 64>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
+                    : launch_correct_t<false, 64>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const double* split, const double* params,
+hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (m.flags & MISTI_CPFIT)
         hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, split, params, lc_raw, nc, lc_out, jafs, status);
+                           m, n_cand, order, split, params, lc_raw, nc, lc_out, jafs, status);
     else
         hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, split, params, lc_raw, nc, lc_out, jafs, status);
+                           m, n_cand, order, split, params, lc_raw, nc, lc_out, jafs, status);
     return hipGetLastError();
 }
 
