@@ -6,10 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (lambda-correction kernel, spectrum kernel,
-replicate/llk kernel) over one batch: the 4 096-point grid of config 2 (64 split
+A step = one pass of the hot path (chain discovery, lambda-correction kernel, spectrum
+kernel, replicate/llk kernel) over one batch: the 4 096-point grid of config 2 (64 split
 indices x 64 rates of one band `-mi 1 4 {st} {r} 1`, `--cpfit`, numT = 128) with
-inputs already resident in HBM.  With N > 1 every rank evaluates its own 4 096-point
+inputs already resident in HBM.  The K timed steps are issued round-robin on `--streams`
+HIP streams (default 8) so that independent batches overlap; the strictly serial rate
+and the per-kernel durations are measured in the same run and reported beside it.  With N > 1 every rank evaluates its own 4 096-point
 grid (weak scaling; the grids differ by a per-rank shift of the rate axis) and the
 log-likelihoods are all-gathered over RCCL each step.  Rank 0 prints ONE JSON line.
 """
@@ -26,6 +28,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _early_streams():
+    """--streams must reach the HIP runtime (hardware queue count) before it initialises."""
+    n = 8
+    for i, a in enumerate(sys.argv):
+        if a == "--streams" and i + 1 < len(sys.argv):
+            n = int(sys.argv[i + 1])
+        elif a.startswith("--streams="):
+            n = int(a.split("=", 1)[1])
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, n)))
+
+
+_early_streams()
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (SURVEY.md 8d)
 
@@ -33,11 +49,14 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="config2", help="config2 (headline) | config3 | config4 | config5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
+    ap.add_argument("--no-serial", action="store_true", help="skip the extra strictly-serial (1 stream) timing")
     return ap.parse_args()
 
 
@@ -79,44 +98,78 @@ def main():
     if world > 1 and w.params is not None:
         # distinct grids per rank (weak scaling): shift the rate axis by a rank-dependent factor
         w.params = w.params * (1.0 + 0.01 * rank)
-    eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
     n, R, P = w.n_cand, int(w.jsfs.shape[0]), w.n_param
     d_split = torch.as_tensor(w.split_time, dtype=torch.float64, device=dev)
     d_par = torch.as_tensor(w.params, dtype=torch.float64, device=dev).contiguous() if P else None
     d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
-    d_llk = torch.empty((n, R), dtype=torch.float64, device=dev)
-    d_jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
-    d_status = torch.empty(n, dtype=torch.int32, device=dev)
     d_all = torch.empty((world * n, R), dtype=torch.float64, device=dev) if world > 1 else None
-    eng.use_stream(torch.cuda.current_stream().cuda_stream)
 
-    def step():
-        eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
-                         d_llk.data_ptr(), d_jafs.data_ptr(), 0, 0, d_status.data_ptr())
-        if world > 1:
-            dist.all_gather_into_tensor(d_all, d_llk)
+    comm_stream = torch.cuda.Stream() if world > 1 else None
+
+    class Lane:
+        """One engine context + its output buffers on one HIP stream."""
+        def __init__(self, stream):
+            self.stream = stream
+            self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
+            self.eng.use_stream(stream.cuda_stream)
+            self.llk = torch.empty((n, R), dtype=torch.float64, device=dev)
+            self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
+            self.status = torch.empty(n, dtype=torch.int32, device=dev)
+            self.gathered = None
+
+        def step(self):
+            if self.gathered is not None:                      # the previous gather of this lane still reads self.llk
+                self.stream.wait_event(self.gathered)
+            self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
+                                  self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
+            if world > 1:
+                # one communicator: gathers are serialised on a dedicated stream, in issue order on every rank
+                done = torch.cuda.Event()
+                done.record(self.stream)
+                comm_stream.wait_event(done)
+                with torch.cuda.stream(comm_stream):
+                    dist.all_gather_into_tensor(d_all, self.llk)
+                    self.gathered = torch.cuda.Event()
+                    self.gathered.record(comm_stream)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    fence()
-    eng.enable_timing(True)
-    eng.kernel_times(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(lanes, timing):
+        """W warmup + K timed steps issued round-robin on `lanes`; returns seconds (max over ranks)."""
+        for i in range(a.warmup):
+            lanes[i % len(lanes)].step()
+        fence()
+        if timing:
+            lanes[0].eng.enable_timing(True)
+            lanes[0].eng.kernel_times(reset=True)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            lanes[i % len(lanes)].step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    n_streams = max(1, a.streams)
+    main_lanes = [Lane(torch.cuda.Stream()) for i in range(n_streams)]
+    dt = timed(main_lanes, timing=False)
+    # strictly serial pass on one stream: per-kernel durations (HIP events on the launch stream) and the serial rate
+    serial = Lane(torch.cuda.current_stream())
+    eng = serial.eng
+    k_serial = max(4, min(a.steps, 16))
+    keep = (a.steps, a.warmup)
+    a.steps, a.warmup = k_serial, 2
+    dt_serial = timed([serial], timing=True)
+    a.steps, a.warmup = keep
     kms, kn = eng.kernel_times(reset=True)
     eng.enable_timing(False)
+    d_llk, d_status = serial.llk, serial.status
 
     status = d_status.cpu().numpy()
     llk = d_llk.cpu().numpy()
@@ -128,7 +181,7 @@ def main():
         "value": value, "unit": "llk evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": w.name, "candidates_per_gpu": n, "replicates": R, "numT": w.numT,
+        "config": {"workload": w.name, "candidates_per_gpu": n, "replicates": R, "numT": w.numT, "streams": n_streams,
                    "parallelism": "candidates sharded per GPU, all_gather of llk (RCCL)" if world > 1 else "1 GPU"},
     }
     if rank == 0:
@@ -156,6 +209,10 @@ def main():
         out["status_fraction"] = {"ok": float(ok.mean()), "correction_failed": float((status == 2).mean()),
                                   "stiff": float((status == 6).mean()), "numeric": float((status == 5).mean())}
         out["spectrum_evals_per_s"] = world * n * a.steps / dt
+        out["serial"] = {"streams": 1, "value": world * n * R * k_serial / dt_serial, "ms_per_step": 1e3 * dt_serial / k_serial, "steps": k_serial,
+                         "note": "the same step issued strictly one after another on one stream: bounded by the longest "
+                                 "lambda-correction chain of the batch (up to ~830 dependent residual evaluations in the runaway "
+                                 "corner of the grid), which overlapping independent batches on several streams hides"}
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----------
         if world == 1 and not a.no_cpu_baseline:
             from oracle.batch import oracle_batch
@@ -169,10 +226,15 @@ def main():
                                              % (len(idx), n, R, wall)}
             # the same sample doubles as an end-to-end parity check of this run
             both = (o_status == 0) & (status[idx] == 0)
-            rel = np.abs(llk[idx][both] - o_llk[both]) / np.abs(o_llk[both])
-            out["parity_vs_oracle_sample"] = {"n": int(both.sum()), "median_rel": float(np.median(rel)) if both.any() else None,
-                                              "frac_within_1e-9": float((rel <= 1e-9).mean()) if both.any() else None,
-                                              "status_agree": float((o_status == status[idx]).mean())}
+            rel = np.abs(llk[idx, 0] - o_llk[:, 0]) / np.abs(o_llk[:, 0])
+            regular = both & (oracle_batch.last_runaway < 10.0)      # the reference itself is determined
+            runaway = both & ~regular
+            out["parity_vs_oracle_sample"] = {
+                "n": int(both.sum()), "status_agree": float((o_status == status[idx]).mean()),
+                "regular": {"n": int(regular.sum()), "max_rel": float(rel[regular].max()) if regular.any() else None,
+                            "frac_within_1e-9": float((rel[regular] <= 1e-9).mean()) if regular.any() else None},
+                "runaway_rate_candidates": {"n": int(runaway.sum()), "max_rel": float(rel[runaway].max()) if runaway.any() else None,
+                                            "note": "reference-indeterminate (corrected rate x interval length >= 10): the reference's own value is noise-driven"}}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -69,7 +69,7 @@ struct misti_ctx {
     DevBuf consts;                      // llh_const per replicate
     DevBuf ws_jafs, ws_status;          // spectra / status when the caller passes NULL
     DevBuf ws_order;                    // dispatch order (heaviest candidates first)
-    DevBuf ws_lc, ws_nc;                // kernel 1 -> kernel 2: unsmoothed two-population rates, nc at the split
+    DevBuf ws_chain_f64, ws_chain_i32, ws_scratch, ws_temp;   // chain buffers (kernel 1 -> kernel 2), discovery scratch
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -166,21 +166,42 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     HIP_TRY(hipSetDevice(c->device));
     if (!d_jafs) { HIP_TRY(c->ws_jafs.reserve((size_t)n_cand * 7 * sizeof(double))); d_jafs = c->ws_jafs.as<double>(); }
     if (!d_status) { HIP_TRY(c->ws_status.reserve((size_t)n_cand * sizeof(int32_t))); d_status = c->ws_status.as<int32_t>(); }
-    HIP_TRY(c->ws_lc.reserve((size_t)n_cand * (c->dm.numT + 1) * 2 * sizeof(double)));
-    HIP_TRY(c->ws_nc.reserve((size_t)n_cand * 2 * sizeof(double)));
-    HIP_TRY(c->ws_order.reserve((size_t)n_cand * sizeof(int32_t)));
-    double* d_raw = c->ws_lc.as<double>();
-    double* d_nc = c->ws_nc.as<double>();
+    if (n_cand > INT32_MAX / 8) return fail(MISTI_E_LIMIT, "n_cand too large for one call");
+    const size_t nc = (size_t)n_cand, numT = (size_t)c->dm.numT;
+    // chain machinery: one allocation, carved below
+    size_t temp_bytes = 0;
+    HIP_TRY(misti::chain_temp_bytes(n_cand, &temp_bytes));
+    const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
+    const size_t i32_n = 1 + 6 * nc + 1;                         // n_chains, rep, len, of, fail_t, fail_status, tail_status
+    const size_t scratch_bytes = nc * 2 * sizeof(uint64_t) + nc * 4 * sizeof(int32_t);
+    HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
+    HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
+    HIP_TRY(c->ws_scratch.reserve(scratch_bytes));
+    HIP_TRY(c->ws_temp.reserve(temp_bytes + 16));
+    HIP_TRY(c->ws_order.reserve(nc * sizeof(int32_t)));
+    misti::ChainBufs cb;
+    {
+        double* d = c->ws_chain_f64.as<double>();
+        cb.lc = d; d += nc * numT * 2;
+        cb.trace = d; d += nc * (numT + 1) * 6;
+        cb.work = d; d += nc * 6;
+        cb.tail_lc = d; d += nc * 2;
+        cb.tail_state = d;
+        int32_t* q = c->ws_chain_i32.as<int32_t>();
+        cb.n_chains = q; q += 2;
+        cb.rep = q; q += nc; cb.len = q; q += nc; cb.of = q; q += nc;
+        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q;
+    }
     int32_t* d_order = c->ws_order.as<int32_t>();
-    if (n_cand > INT32_MAX) return fail(MISTI_E_LIMIT, "n_cand exceeds 2^31-1");
-    HIP_TRY(misti::launch_order(n_cand, d_split, c->dm.numT, d_order, c->stream));
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY(misti::launch_correct(c->dm, n_cand, d_order, d_split, d_params, d_raw, d_nc, d_pr, d_status, c->stream));
+    HIP_TRY(misti::launch_order(n_cand, d_split, c->dm.numT, d_order, c->stream));
+    HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->ws_scratch.p, c->ws_temp.p, temp_bytes, c->stream));
+    HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, c->stream));
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     if (int r = record_begin(c, 1, &a, &b)) return r;
-    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, d_raw, d_nc, d_lc, d_jafs, d_status, c->stream));
+    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->stream));
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0) {
@@ -316,7 +337,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_lc, &c->ws_nc, &c->ws_order, &c->st_split, &c->st_params, &c->st_jsfs,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->st_split, &c->st_params, &c->st_jsfs,
                     &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     for (int w = 0; w < 3; ++w)

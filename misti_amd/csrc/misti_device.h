@@ -41,13 +41,31 @@ struct DevModel {
     misti_pulse_t pulses[MISTI_MAX_PULSES];
 };
 
+// Device buffers of the chain machinery (see correct_kernel).
+struct ChainBufs {
+    int32_t* n_chains;      // [1]
+    int32_t* rep;           // [n] chain -> a member candidate (its parameters)
+    int32_t* len;           // [n] chain -> number of full intervals needed (max over members)
+    int32_t* of;            // [n] candidate -> chain
+    double* lc;             // [n][numT][2]     per chain: corrected rates, unsmoothed
+    double* trace;          // [n][numT+1][6]   per chain: pair state before interval t (.Pr layout)
+    int32_t* fail_t;        // [n] per chain: first failing interval, INT_MAX if none
+    int32_t* fail_status;   // [n]
+    double* work;           // [n][6] per chain: work counters
+    double* tail_lc;        // [n][2] per candidate with a fractional split
+    double* tail_state;     // [n][6]
+    int32_t* tail_status;   // [n]
+};
+
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
 hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream);
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream);
+hipError_t chain_temp_bytes(int64_t n, size_t* bytes);
+hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, ChainBufs cb,
+                                  void* scratch, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                           const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream);
+                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
                       const double* consts, double* llk, int unfolded, hipStream_t stream);

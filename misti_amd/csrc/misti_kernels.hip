@@ -28,6 +28,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <hipcub/hipcub.hpp>
+
 #include "misti_device.h"
 
 namespace misti {
@@ -58,7 +60,14 @@ __device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(
 // chosen at launch from the batch size (few candidates per wave while the chip is not full).
 // Everything "uniform" is uniform within a group; cross-lane traffic never leaves a group.
 template <int GROUP>
-__device__ __forceinline__ double gbcast(double v, int j) { return __shfl(v, (lane_id() & ~(GROUP - 1)) + j, 64); }
+__device__ __forceinline__ double gbcast(double v, int j) {
+    if (GROUP == 64) {                       // one candidate per wave: scalar broadcast, no LDS crossbar round trip
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+        return __hiloint2double(hi, lo);
+    }
+    return __shfl(v, (lane_id() & ~(GROUP - 1)) + j, 64);
+}
 
 __device__ __forceinline__ void lds_fence() {
     // one wave owns its LDS slice: ordering only has to be kept by the compiler
@@ -181,13 +190,34 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
-    const int nsub = 1;
-    const double sc = 1.0;
-    double qs = q, nbs = nbmax;
-    double n00 = qs - d0 * sc, n11 = qs - d1 * sc, n22 = qs - d2 * sc;
-    double n02 = mu1 * sc, n12 = mu0 * sc, n20 = 2.0 * mu0 * sc, n21 = 2.0 * mu1 * sc;
+    if (2.0 * nbmax <= 0.5) {
+        // small norm (the usual case: rate x interval length << 1): plain Taylor series of exp(M) v.
+        // No shift, no exp(); cancellation is bounded by e^0.5 ulp, and a decoupled component again
+        // sees identical arithmetic in every forward-difference lane.
+        double p0 = v[0], p1 = v[1], p2 = v[2];
+        double a0 = p0, a1 = p1, a2 = p2;
+        double b = 1.0;
+        const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
+        for (int k = 1; k < 40; ++k) {
+            const double inv = c_inv[k];
+            const double t0 = (mu1 * p2 - d0 * p0) * inv;
+            const double t1 = (mu0 * p2 - d1 * p1) * inv;
+            const double t2 = ((twomu0 * p0 + twomu1 * p1) - d2 * p2) * inv;
+            p0 = t0; p1 = t1; p2 = t2;
+            a0 += p0; a1 += p1; a2 += p2;
+            b *= 2.0 * nbmax * inv;              // ||M||_1 <= 2 (q + neg)
+            dg.terms += 1;
+            if (b < 1e-19) break;
+        }
+        v[0] = a0; v[1] = a1; v[2] = a2;
+        if (!ok) { v[0] = v[1] = v[2] = NAN; }
+        return;
+    }
+    const double qs = q, nbs = nbmax;
+    double n00 = qs - d0, n11 = qs - d1, n22 = qs - d2;
+    double n02 = mu1, n12 = mu0, n20 = 2.0 * mu0, n21 = 2.0 * mu1;
     double eq = exp(-qs);
-    for (int s = 0; s < nsub; ++s) {
+    {
         double p0 = eq * v[0], p1 = eq * v[1], p2 = eq * v[2];
         double a0 = p0, a1 = p1, a2 = p2;
         double b = 1.0;                    // nbs^k / k! bounds the k-th term for every lane
@@ -698,21 +728,26 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
 
 // Kernel 1: lambda correction of the two-population intervals (CorrectLambdas loop t < splitT,
 // MigrationInference.py:307-354; SolveLambdaSystem, CorrectLambda.py:266-317).
-// GROUP lanes per candidate, 8 candidates per wavefront, no LDS.  Each candidate runs its own
-// resumable state machine: one pass of the loop = one residual batch (trial point + its
-// forward-difference points) + the trust-region bookkeeping of trf_no_bounds (trf.py:401-560),
-// so the candidates of a wavefront never wait for each other interval by interval.
-// Writes the unsmoothed corrected rates of the two-population intervals lc_raw[cand][numT+1][2],
-// the non-coalescence sums nc[cand][2] at the split (:353-354), the pair-state trace, the status.
-template <bool CPFIT, int GROUP>
+//
+// The recursion over intervals does not depend on the split time except for where it stops:
+// candidates with the same parameter vector share one CHAIN (chain discovery below), computed
+// once up to the largest split index of its members - in a split x rate sweep 64 chains instead of
+// 4 096.  A fractional split shortens the candidate's last two-population interval; that one
+// interval is a TAIL, run per candidate from the chain's state (second launch, TAIL = true).
+//
+// GROUP lanes per work item (6 carry the residual evaluations), no LDS beyond the staged grid.
+// Each item runs its own resumable state machine: one pass of the loop = one residual batch
+// (trial point + its forward-difference points) + the trust-region bookkeeping of
+// trf_no_bounds (trf.py:401-560), so the items of a wavefront never wait for each other
+// interval by interval.
+template <bool CPFIT, int GROUP, bool TAIL>
 __global__ __launch_bounds__(64)
-void correct_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
-                    double* __restrict__ lc_raw, double* __restrict__ nc_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
+void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
     const int lane = lane_id();
     const int sub = lane & (GROUP - 1);
     const int64_t slot = ((int64_t)blockIdx.x * (64 / GROUP)) + (lane / GROUP);
     // the shared grid (interval lengths, PSMC rates) staged in LDS: every pass of the state
-    // machine of some candidate reads it, and an L2 round trip per read dominated the kernel
+    // machine of some item reads it, and an L2 round trip per read dominated the kernel
     extern __shared__ double lds[];
     {
         const int nt = m.numT - 1, nl = 2 * m.numT;
@@ -720,45 +755,61 @@ void correct_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ orde
         for (int i = lane; i < nl; i += 64) lds[nt + i] = m.lh[i];
     }
     __syncthreads();
-    const bool in_range = slot < n_cand;
-    const int64_t cand = order[in_range ? slot : n_cand - 1];      // heaviest (largest split) first
-    const int64_t cand_c = cand;
-    const int lc_rows = m.numT + 1;
-    const double* par = params ? params + cand_c * m.n_param : nullptr;
+    const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
+    if (slot >= n_live) return;
+    const int64_t cand = TAIL ? slot : (int64_t)cb.rep[slot];      // whose parameters
+    const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
-    int status = setup_candidate(m, split_time[cand_c], par, G);
+    int status;
+    int t = 0;
+    double* lc_w;     // lc_w[2 t + k]        corrected rates of interval t
+    double* tr_w;     // tr_w[6 (t + 1) + j]  pair state after interval t
+    PairState ps;
+    if (!TAIL) {
+        status = MISTI_OK;
+        for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
+        G.numT0 = m.numT; G.numT = m.numT; G.split = cb.len[slot]; G.ins = -1; G.frac = 0.0;
+        lc_w = cb.lc + slot * (int64_t)m.numT * 2;
+        tr_w = cb.trace + slot * (int64_t)(m.numT + 1) * 6;
+        ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
+        ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
+        if (sub == 0) { tr_w[0] = 1; tr_w[1] = 0; tr_w[2] = 0; tr_w[3] = 1; tr_w[4] = 0; tr_w[5] = 0; }
+    } else {
+        status = setup_candidate(m, split_time[cand], par, G);
+        if (sub == 0) cb.tail_status[cand] = MISTI_OK;
+        if (status != MISTI_OK || G.ins < 0) return;               // nothing to do: no fractional split
+        const int64_t ch = cb.of[cand];
+        if (cb.fail_t[ch] < G.ins) return;                         // the chain failed before this candidate's tail
+        t = G.ins;
+        const double* r = cb.trace + (ch * (int64_t)(m.numT + 1) + t) * 6;
+        ps.p[0][0] = r[0]; ps.p[1][0] = r[1]; ps.p[0][1] = r[2]; ps.p[1][1] = r[3]; ps.p[0][2] = r[4]; ps.p[1][2] = r[5];
+        lc_w = cb.tail_lc + 2 * cand - 2 * (int64_t)t;
+        tr_w = cb.tail_state + 6 * cand - 6 * (int64_t)(t + 1);
+    }
     G.times = lds; G.lh = lds + (m.numT - 1);
-    if (!in_range) return;
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
     mod.cache();
     const bool correct = !(m.flags & MISTI_TRUE_EPS);
-    double* pr_c = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
-    double* lc_c = lc_raw + cand * (int64_t)lc_rows * 2;
     const int max_nfev = 200;                    // 100 * n (least_squares.py)
-
     Diag dg;
-    PairState ps;
-    ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
-    ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
-    if (status == MISTI_OK && pr_c && sub == 0) { pr_c[0] = 1; pr_c[1] = 0; pr_c[2] = 0; pr_c[3] = 1; pr_c[4] = 0; pr_c[5] = 0; }
 
     // solver state of the interval in progress
     PairProblem pb;
     double T = 0.0;
     double x[2] = {0, 0}, f[2] = {0, 0}, J[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0}, xe[2] = {0, 0}, p[2] = {0, 0}, vk[3] = {0, 0, 0};
     double cost = 0.0, Delta = 0.0, alpha = 0.0, predicted = 0.0;
-    int nfev = 0, t = 0;
+    int nfev = 0;
     bool first = false, in_solve = false, have_sv = false;
     Svd2 sv;
 
     auto finish_interval = [&](double lc0, double lc1) -> bool {       // :345-350; false = correction failed
-        if (sub == 0) { lc_c[2 * t] = lc0; lc_c[2 * t + 1] = lc1; }
+        if (sub == 0) { lc_w[2 * t] = lc0; lc_w[2 * t + 1] = lc1; }
         if (!(lc0 > 0) || !(lc1 > 0)) {
             status = (isnan(lc0) || isnan(lc1)) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
             return false;
         }
-        if (pr_c && sub == 0) {
-            double* r = pr_c + 6 * (t + 1);
+        if (sub == 0) {
+            double* r = tr_w + 6 * (t + 1);
             r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
         }
         ++t;
@@ -916,18 +967,19 @@ void correct_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ orde
         }
         STAMP(c_book)
     }
-    if (status == MISTI_OK && dg.guard) status = MISTI_NUMERIC;
-    if (pr_c && sub == 0) {                       // last row of the trace buffer: work counters of this candidate
-        double* r = pr_c + 6 * (m.numT + 1);
-        r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = 0.0;
-#ifdef MISTI_STAMP
-        r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
-#endif
-    }
+    if (dg.guard) { status = MISTI_NUMERIC; if (!TAIL) t = 0; }       // an overflowing iterate was cut off somewhere
     if (sub == 0) {
-        status_out[cand] = status;
-        nc_out[2 * cand] = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];       // :353-354: a probability, used as a log below
-        nc_out[2 * cand + 1] = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
+        if (!TAIL) {
+            cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
+            cb.fail_status[slot] = status;
+            double* r = cb.work + slot * 6;
+            r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = 0.0;
+#ifdef MISTI_STAMP
+            r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
+#endif
+        } else {
+            cb.tail_status[cand] = status;
+        }
     }
 }
 
@@ -938,8 +990,8 @@ void correct_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ orde
 template <bool CPFIT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
-                     const double* __restrict__ lc_raw, const double* __restrict__ nc_in, double* __restrict__ lc_out,
-                     double* __restrict__ jafs_out, int32_t* __restrict__ status_io) {
+                     ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
+                     double* __restrict__ jafs_out, int32_t* __restrict__ status_out) {
     extern __shared__ double lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -949,30 +1001,57 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     const int lc_rows = m.numT + 1;
     double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
     double* lcb = xbuf + 128;
-    int status = status_io[cand];
     const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
-    (void)setup_candidate(m, split_time[cand], par, G);
+    int status = setup_candidate(m, split_time[cand], par, G);
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
     mod.cache();
-    double* lc_o = lc_out ? lc_out + cand * (int64_t)lc_rows * 2 : nullptr;
-    if (status != MISTI_OK) {
-        if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
-        if (lc_o) {                          // partial rates (up to the failing interval) for diagnostics
-            const double* src = lc_raw + cand * (int64_t)lc_rows * 2;
-            int upto = (status == MISTI_CORR_FAILED || status == MISTI_NUMERIC) ? 2 * G.split : 0;
-            for (int i = lane; i < 2 * lc_rows; i += 64) lc_o[i] = (i < upto && i < 2 * m.numT) ? src[i] : 0.0;
+    // ---- this candidate's share of its chain (+ its own tail interval after a fractional split)
+    const int64_t ch = cb.of[cand];
+    const int nfull = (G.ins >= 0) ? G.ins : G.split;          // intervals taken from the chain
+    const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
+    const double* tr_ch = cb.trace + ch * (int64_t)(m.numT + 1) * 6;
+    int have = 0;                                               // intervals with a corrected rate (for diagnostics)
+    if (status == MISTI_OK) {
+        const int ft = cb.fail_t[ch];
+        if (ft < nfull) { status = cb.fail_status[ch]; have = ft + 1; }
+        else {
+            have = nfull;
+            if (G.ins >= 0) { const int ts = cb.tail_status[cand]; have = nfull + 1; if (ts != MISTI_OK) status = ts; }
         }
+    }
+    double* lc_o = lc_out ? lc_out + cand * (int64_t)lc_rows * 2 : nullptr;
+    double* pr_o = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
+    if (pr_o) {
+        // .Pr trace (MigrationInference.py:309,350): rows 0..split from the chain (+ tail); last row = work counters
+        const int rows = (status == MISTI_OK) ? G.split + 1 : (have > nfull ? nfull + 1 : (have > 0 ? have : (status == MISTI_OK ? 1 : 0)));
+        for (int i = lane; i < (m.numT + 2) * 6; i += 64) {
+            const int r = i / 6, j = i - 6 * r;
+            double v = 0.0;
+            if (r == m.numT + 1) v = cb.work[ch * 6 + j];
+            else if (r < rows) v = (G.ins >= 0 && r == nfull + 1) ? cb.tail_state[cand * 6 + j] : tr_ch[6 * r + j];
+            pr_o[i] = v;
+        }
+    }
+    if (status != MISTI_OK) {
+        if (lane == 0) status_out[cand] = status;
+        if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
+        if (lc_o)                            // partial rates (up to the failing interval) for diagnostics
+            for (int i = lane; i < 2 * lc_rows; i += 64) {
+                const int t = i >> 1;
+                lc_o[i] = (t < have && t < nfull) ? lc_ch[i] : (t < have && t == nfull && G.ins >= 0) ? cb.tail_lc[2 * cand + (i & 1)] : 0.0;
+            }
         return;
     }
-    {
-        const double* src = lc_raw + cand * (int64_t)lc_rows * 2;
-        for (int i = lane; i < 2 * lc_rows; i += 64) lcb[i] = (i < 2 * G.split) ? src[i] : 0.0;
+    for (int i = lane; i < 2 * lc_rows; i += 64) {
+        const int t = i >> 1;
+        lcb[i] = (t < nfull) ? lc_ch[i] : (t == nfull && G.ins >= 0) ? cb.tail_lc[2 * cand + (i & 1)] : 0.0;
     }
     lds_fence();
     {
         // ---- post-split rates (:355-376); nc is a probability used as a log ----
-        const double nc0 = nc_in[2 * cand], nc1 = nc_in[2 * cand + 1];
+        const double* stt = (G.ins >= 0) ? cb.tail_state + 6 * cand : tr_ch + 6 * nfull;    // pair state at the split
+        const double nc0 = (stt[0] + stt[2]) + stt[4], nc1 = (stt[1] + stt[3]) + stt[5];     // :353-354
         const double delta = nc1 - nc0;
         const double ed = exp(delta);
         const int last = G.numT - 1;
@@ -1213,12 +1292,89 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         }
     }
     // ---- outputs ------------------------------------------------------------
-    if (lane == 0 && status != MISTI_OK) status_io[cand] = status;
+    if (lane == 0) status_out[cand] = status;
     if (lane < 7) {
         double v = NAN;
         for (int c = 0; c < 7; ++c) if (lane == c) v = jafs[c];
         jafs_out[cand * 7 + lane] = (status == MISTI_OK) ? v : NAN;
     }
+}
+
+// ---- chain discovery: candidates with bitwise identical parameter vectors share a chain ----
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void chain_key_kernel(int64_t n, int P, const double* __restrict__ params, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t h = 0x243f6a8885a308d3ull;
+    for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(params[i * P + k]));
+    keys[i] = h;
+    vals[i] = (int32_t)i;
+}
+// head[i] = 1 where the i-th sorted candidate starts a run of identical parameter vectors
+// (equal hashes are verified, so a hash collision only costs sharing, never correctness)
+__global__ void chain_head_kernel(int64_t n, int P, const double* __restrict__ params, const uint64_t* __restrict__ keys,
+                                  const int32_t* __restrict__ idx, int32_t* __restrict__ head) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int h = 1;
+    if (i > 0 && keys[i] == keys[i - 1]) {
+        h = 0;
+        const double* a = params + (int64_t)idx[i] * P;
+        const double* b = params + (int64_t)idx[i - 1] * P;
+        for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) h = 1;
+    }
+    head[i] = h;
+}
+__global__ void chain_assign_kernel(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ head, const int32_t* __restrict__ scan,
+                                    const double* __restrict__ split_time, int numT, ChainBufs cb) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ch = scan[i] - 1;
+    const int c = idx[i];
+    cb.of[c] = ch;
+    if (head[i]) cb.rep[ch] = c;
+    const double st = split_time[c];
+    int need = 0;
+    if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
+    atomicMax(&cb.len[ch], need);
+    if (i == n - 1) cb.n_chains[0] = scan[i];
+}
+
+hipError_t chain_temp_bytes(int64_t n, size_t* bytes) {
+    size_t a = 0, b = 0;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+    if (e != hipSuccess) return e;
+    e = hipcub::DeviceScan::InclusiveSum(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+    *bytes = a > b ? a : b;
+    return e;
+}
+
+// scratch: keys[2n] u64 | vals[2n] i32 | head[n] i32 | scan[n] i32 ; temp: hipcub storage
+hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, ChainBufs cb,
+                                  void* scratch, void* temp, size_t temp_bytes, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    uint64_t* keys = (uint64_t*)scratch;
+    uint64_t* keys2 = keys + n;
+    int32_t* vals = (int32_t*)(keys2 + n);
+    int32_t* vals2 = vals + n;
+    int32_t* head = vals2 + n;
+    int32_t* scan = head + n;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipError_t e = hipMemsetAsync(cb.len, 0, n * sizeof(int32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chain_key_kernel, dim3(nb), dim3(256), 0, stream, n, P, params, keys, vals);
+    e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)n, 0, 64, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chain_head_kernel, dim3(nb), dim3(256), 0, stream, n, P, params, keys2, vals2, head);
+    e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, head, scan, (int)n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(chain_assign_kernel, dim3(nb), dim3(256), 0, stream, n, vals2, head, scan, split, numT, cb);
+    return hipGetLastError();
 }
 
 // Dispatch order: candidates sorted by descending split index (counting sort, one workgroup).
@@ -1316,52 +1472,53 @@ hipError_t upload_tables(const DevTables& t) {
 
 size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
 
-template <bool CPFIT, int GROUP>
-static void launch_correct_t(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                             double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
+template <bool CPFIT, int GROUP, bool TAIL>
+static void launch_correct_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
     const int per_wave = 64 / GROUP;
-    dim3 grid((unsigned)((n_cand + per_wave - 1) / per_wave));
+    dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
     const size_t lds = (size_t)(3 * m.numT - 1) * sizeof(double);
-    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, order, split, params, lc_raw, nc, pr, status);
+    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP, TAIL>), grid, dim3(64), lds, stream, m, n_items, cb, split, params);
 }
 
-// Candidates per wavefront: 8 when the batch fills the chip several times over, fewer for small
-// batches (less divergence between the candidates of a wave, more wavefronts to overlap latency).
+// Work items per wavefront: 8 when the batch fills the chip several times over, fewer for small
+// batches (less divergence between the items of a wave, more wavefronts to overlap latency).
 int correct_cands_per_wave(int64_t n_cand) {
     static const int forced = [] { const char* e = getenv("MISTI_CANDS_PER_WAVE"); return e ? atoi(e) : 0; }();
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     int cpw = 8;
-    while (cpw > 1 && n_cand / cpw < 2048) cpw /= 2;
+    while (cpw > 1 && n_cand / cpw < 4096) cpw /= 2;      // one item per wave until the chip holds two waves per SIMD
     return cpw;
 }
 
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                          double* lc_raw, double* nc, double* pr, int32_t* status, hipStream_t stream) {
-    if (n_cand <= 0) return hipSuccess;
+template <bool TAIL>
+static void launch_correct_mode(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
     const bool cp = m.flags & MISTI_CPFIT;
-    switch (correct_cands_per_wave(n_cand)) {
-        case 8: cp ? launch_correct_t<true, 8>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
-                   : launch_correct_t<false, 8>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
-        case 4: cp ? launch_correct_t<true, 16>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
-                   : launch_correct_t<false, 16>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
-        case 2: cp ? launch_correct_t<true, 32>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
-                   : launch_correct_t<false, 32>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
-        default: cp ? launch_correct_t<true, 64>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream)
-                    : launch_correct_t<false, 64>(m, n_cand, order, split, params, lc_raw, nc, pr, status, stream); break;
+    switch (correct_cands_per_wave(n_items)) {
+        case 8: cp ? launch_correct_t<true, 8, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 8, TAIL>(m, n_items, cb, split, params, stream); break;
+        case 4: cp ? launch_correct_t<true, 16, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 16, TAIL>(m, n_items, cb, split, params, stream); break;
+        case 2: cp ? launch_correct_t<true, 32, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 32, TAIL>(m, n_items, cb, split, params, stream); break;
+        default: cp ? launch_correct_t<true, 64, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 64, TAIL>(m, n_items, cb, split, params, stream); break;
     }
+}
+
+// chains (the number of live chains is read on the device: slots beyond it exit at once), then tails
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    launch_correct_mode<false>(m, n_cand, cb, split, params, stream);
+    launch_correct_mode<true>(m, n_cand, cb, split, params, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                           const double* lc_raw, const double* nc, double* lc_out, double* jafs, int32_t* status, hipStream_t stream) {
+                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (m.flags & MISTI_CPFIT)
         hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, lc_raw, nc, lc_out, jafs, status);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status);
     else
         hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, lc_raw, nc, lc_out, jafs, status);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status);
     return hipGetLastError();
 }
 
