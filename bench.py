@@ -61,14 +61,24 @@ def parse():
 
 
 def algorithmic_bytes(w, n_rep):
-    """HBM bytes the algorithm needs per candidate, per kernel:
-    correction: split 8 + params 8P in, lc 16(numT+1) + status 4 out;
-    spectrum:   split 8 + params 8P + lc 16(numT+1) + status 4 in, JAFS 56 out;
+    """HBM bytes the algorithm needs per launch, per kernel.
+
+    correction: one chain per distinct parameter vector, computed up to the largest split index of
+                its members: 8P in; per interval 16 B of rates + 48 B of pair state out;
+    spectrum:   per candidate split 8 + params 8P in, its share of the chain 16 B per two-population
+                interval + 48 B state, JAFS 56 + status 4 out;
     llk:        JAFS 56 + status 4 in (the replicate table is shared), 8 per replicate out."""
-    P, numT = w.n_param, w.numT
-    return {"correct": 8 + 8 * P + 16 * (numT + 1) + 4,
-            "spectrum": 8 + 8 * P + 16 * (numT + 1) + 4 + 56,
-            "llk": 60 + 8 * n_rep}
+    P, n = w.n_param, w.n_cand
+    s_int = np.floor(w.split_time).astype(int)
+    if w.params is None:
+        chains = {(): int(s_int.max())}
+    else:
+        chains = {}
+        for row, s in zip(map(tuple, w.params), s_int):
+            chains[row] = max(chains.get(row, 0), int(s))
+    correct = sum(8 * P + 64 * L for L in chains.values())
+    spectrum = int((8 + 8 * P + 16 * s_int + 48 + 60).sum())
+    return {"correct": correct, "spectrum": spectrum, "llk": n * (60 + 8 * n_rep), "n_chains": len(chains)}
 
 
 def main():
@@ -189,7 +199,7 @@ def main():
         per = {k: (kms[k] / kn[k] if kn[k] else 0.0) for k in kms}          # ms per launch, HIP events on the launch stream
         dom = max(("correct", "spectrum"), key=lambda k: per[k])
         ab = algorithmic_bytes(w, R)
-        achieved = ab[dom] * n / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
+        achieved = ab[dom] / (per[dom] * 1e-3) / 1e9 if per[dom] > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
@@ -201,10 +211,11 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "algorithmic_bytes_per_candidate": ab[dom], "candidates_per_launch": n,
+                           "algorithmic_bytes_per_launch": ab[dom], "candidates_per_launch": n, "chains_per_launch": ab["n_chains"],
                            "ms_per_launch": per,
-                           "note": "the path is neither HBM- nor MFMA-bound (SURVEY 8d): ~2 KB per candidate against ~1e5 dependent fp64 "
-                                   "operations; the binding resources are fp64 VALU issue and LDS/dependent-issue latency"}
+                           "note": "the path is neither HBM- nor MFMA-bound (SURVEY 8d): ~1 KB per candidate against ~1e5 dependent fp64 "
+                                   "operations; the correction kernel is bound by the dependent-issue latency of its longest chain "
+                                   "(serial trust-region iterations of the reference's solver), the spectrum kernel by fp64 VALU issue + LDS latency"}
         ok = status == 0
         out["status_fraction"] = {"ok": float(ok.mean()), "correction_failed": float((status == 2).mean()),
                                   "stiff": float((status == 6).mean()), "numeric": float((status == 5).mean())}
@@ -227,14 +238,14 @@ def main():
             # the same sample doubles as an end-to-end parity check of this run
             both = (o_status == 0) & (status[idx] == 0)
             rel = np.abs(llk[idx, 0] - o_llk[:, 0]) / np.abs(o_llk[:, 0])
-            regular = both & (oracle_batch.last_runaway < 10.0)      # the reference itself is determined
+            regular = both & (oracle_batch.last_runaway < 5.0)       # the reference itself is determined
             runaway = both & ~regular
             out["parity_vs_oracle_sample"] = {
                 "n": int(both.sum()), "status_agree": float((o_status == status[idx]).mean()),
                 "regular": {"n": int(regular.sum()), "max_rel": float(rel[regular].max()) if regular.any() else None,
                             "frac_within_1e-9": float((rel[regular] <= 1e-9).mean()) if regular.any() else None},
                 "runaway_rate_candidates": {"n": int(runaway.sum()), "max_rel": float(rel[runaway].max()) if runaway.any() else None,
-                                            "note": "reference-indeterminate (corrected rate x interval length >= 10): the reference's own value is noise-driven"}}
+                                            "note": "reference-indeterminate (corrected rate x interval length >= 5): the reference's own value is noise-driven"}}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
