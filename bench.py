@@ -10,7 +10,7 @@ A step = one pass of the hot path (chain discovery, lambda-correction kernel, sp
 kernel, replicate/llk kernel) over one batch: the 4 096-point grid of config 2 (64 split
 indices x 64 rates of one band `-mi 1 4 {st} {r} 1`, `--cpfit`, numT = 128) with
 inputs already resident in HBM.  The K timed steps are issued round-robin on `--streams`
-HIP streams (default 8) so that independent batches overlap; the strictly serial rate
+HIP streams (default 16) so that independent batches overlap; the strictly serial rate
 and the per-kernel durations are measured in the same run and reported beside it.  With N > 1 every rank evaluates its own 4 096-point
 grid (weak scaling; the grids differ by a per-rank shift of the rate axis) and the
 log-likelihoods are all-gathered over RCCL each step.  Rank 0 prints ONE JSON line.
@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 def _early_streams():
     """--streams must reach the HIP runtime (hardware queue count) before it initialises."""
-    n = 8
+    n = 16
     for i, a in enumerate(sys.argv):
         if a == "--streams" and i + 1 < len(sys.argv):
             n = int(sys.argv[i + 1])
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--workload", default="config2", help="config2 (headline) | config3 | config4 | config5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=8,
+    ap.add_argument("--streams", type=int, default=16,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
     ap.add_argument("--no-serial", action="store_true", help="skip the extra strictly-serial (1 stream) timing")
     return ap.parse_args()
