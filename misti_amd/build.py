@@ -31,13 +31,11 @@ def build(force=False, verbose=False, extra=()):
     """Compile the kernels and the C-ABI layer into misti_amd/csrc/libmisti_hip.so."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
     cmd += list(extra)
-    if os.environ.get("MISTI_STAMP"):
+    if os.environ.get("MISTI_STAMP"):          # diagnostic build: per-section cycle stamps in the correction kernel
         cmd += ["-DMISTI_STAMP=1"]
-    if os.environ.get("MISTI_ABLATE"):
-        cmd += ["-DMISTI_ABLATE=" + os.environ["MISTI_ABLATE"]]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB + ".tmp"]
     if verbose:

@@ -145,7 +145,7 @@ struct Model {
 // v <- exp(M) v by uniformisation.  Every lane carries its own (l, v); the trip
 // count is wave-uniform (bound from the largest q in the wave).
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
-struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0; };
+struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0; };
 // q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
 // base point and both forward-difference points).  M = N - q I with N >= 0.  When a state is
 // numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway rate
@@ -198,8 +198,10 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         double a0 = p0, a1 = p1, a2 = p2;
         double b = 1.0;
         const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
-        for (int k = 1; k < 40; ++k) {
-            const double inv = c_inv[k];
+        double inv_next = c_inv[1];                  // reciprocal of the NEXT term is fetched one term ahead:
+        for (int k = 1; k < 40; ++k) {               // the scalar-cache round trip would otherwise stall every term
+            const double inv = inv_next;
+            inv_next = c_inv[k + 1];
             const double t0 = (mu1 * p2 - d0 * p0) * inv;
             const double t1 = (mu0 * p2 - d1 * p1) * inv;
             const double t2 = ((twomu0 * p0 + twomu1 * p1) - d2 * p2) * inv;
@@ -221,8 +223,10 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         double p0 = eq * v[0], p1 = eq * v[1], p2 = eq * v[2];
         double a0 = p0, a1 = p1, a2 = p2;
         double b = 1.0;                    // nbs^k / k! bounds the k-th term for every lane
+        double inv_next = c_inv[1];
         for (int k = 1; k < 200; ++k) {
-            double inv = c_inv[k];
+            const double inv = inv_next;
+            inv_next = c_inv[k + 1];
             double t0 = (n00 * p0 + n02 * p2) * inv;
             double t1 = (n11 * p1 + n12 * p2) * inv;
             double t2 = (n20 * p0 + n21 * p1 + n22 * p2) * inv;
@@ -255,6 +259,27 @@ __device__ __forceinline__ void solve3(const double M[3][3], const double b[3], 
     x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) * id;
 }
 
+// Reciprocal / square root for the solver's bookkeeping: hardware seed + Newton steps, ~1 ulp,
+// a third of the instructions of the correctly rounded forms (no denormal/overflow scaling:
+// every operand here is a normal-range quantity or the result is tested for finiteness anyway).
+__device__ __forceinline__ double rcp64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double sqrt64(double x) {
+    if (!(x > 0.0)) return x == 0.0 ? 0.0 : sqrt(x);      // 0, negative, NaN: exact library semantics
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
 // ------------------------------------------------------- least squares -------
 // SciPy's trust-region-reflective solver for the 2x2 systems of the
 // lambda-correction, restated so that the ITERATION SEQUENCE matches
@@ -282,9 +307,9 @@ __device__ __forceinline__ Svd2 svd_mx2(const double A[MROWS][2], const double f
     for (int r = 0; r < MROWS; ++r) { al += A[r][0] * A[r][0]; be += A[r][1] * A[r][1]; ga += A[r][0] * A[r][1]; }
     double c = 1.0, sn = 0.0;
     if (ga != 0.0) {
-        double zeta = (be - al) / (2.0 * ga);
-        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        c = 1.0 / sqrt(1.0 + t * t);
+        double zeta = (be - al) * rcp64(2.0 * ga);
+        double t = copysign(1.0, zeta) * rcp64(fabs(zeta) + sqrt64(1.0 + zeta * zeta));
+        c = rcp64(sqrt64(1.0 + t * t));
         sn = c * t;
     }
     double n1 = 0, n2 = 0, f1 = 0, f2 = 0;
@@ -294,9 +319,9 @@ __device__ __forceinline__ Svd2 svd_mx2(const double A[MROWS][2], const double f
         n1 += a1 * a1; n2 += a2 * a2; f1 += a1 * f[r]; f2 += a2 * f[r];
     }
     Svd2 o;
-    double s1 = sqrt(n1), s2 = sqrt(n2);
+    double s1 = sqrt64(n1), s2 = sqrt64(n2);
     double v1[2] = {c, -sn}, v2[2] = {sn, c};
-    double u1 = s1 > 0 ? f1 / s1 : 0.0, u2 = s2 > 0 ? f2 / s2 : 0.0;
+    double u1 = s1 > 0 ? f1 * rcp64(s1) : 0.0, u2 = s2 > 0 ? f2 * rcp64(s2) : 0.0;
     if (s1 >= s2) { o.s[0] = s1; o.s[1] = s2; o.V[0][0] = v1[0]; o.V[1][0] = v1[1]; o.V[0][1] = v2[0]; o.V[1][1] = v2[1]; o.uf[0] = u1; o.uf[1] = u2; }
     else          { o.s[0] = s2; o.s[1] = s1; o.V[0][0] = v2[0]; o.V[1][0] = v2[1]; o.V[0][1] = v1[0]; o.V[1][1] = v1[1]; o.uf[0] = u2; o.uf[1] = u1; }
     return o;
@@ -307,37 +332,38 @@ __device__ __forceinline__ void solve_tr(const Svd2& d, int m, double Delta, dou
     double suf0 = d.s[0] * d.uf[0], suf1 = d.s[1] * d.uf[1];
     bool full_rank = (m >= 2) && (d.s[1] > LSQ_EPS * m * d.s[0]);
     if (full_rank) {
-        double a = d.uf[0] / d.s[0], b = d.uf[1] / d.s[1];
+        double a = d.uf[0] * rcp64(d.s[0]), b = d.uf[1] * rcp64(d.s[1]);
         p[0] = -(d.V[0][0] * a + d.V[0][1] * b);
         p[1] = -(d.V[1][0] * a + d.V[1][1] * b);
-        if (sqrt(p[0] * p[0] + p[1] * p[1]) <= Delta) { alpha = 0.0; return; }
+        if (p[0] * p[0] + p[1] * p[1] <= Delta * Delta) { alpha = 0.0; return; }
     }
-    double alpha_upper = sqrt(suf0 * suf0 + suf1 * suf1) / Delta;
+    const double rDelta = rcp64(Delta);
+    double alpha_upper = sqrt64(suf0 * suf0 + suf1 * suf1) * rDelta;
     double s0s = d.s[0] * d.s[0], s1s = d.s[1] * d.s[1];
     auto phi_fn = [&](double al, double& phi, double& dphi) {
-        double e0 = s0s + al, e1 = s1s + al;
-        double a = suf0 / e0, b = suf1 / e1;
-        double pn = sqrt(a * a + b * b);
+        double r0 = rcp64(s0s + al), r1 = rcp64(s1s + al);
+        double a = suf0 * r0, b = suf1 * r1;
+        double pn = sqrt64(a * a + b * b);
         phi = pn - Delta;
-        dphi = -(suf0 * suf0 / (e0 * e0 * e0) + suf1 * suf1 / (e1 * e1 * e1)) / pn;
+        dphi = -(a * a * r0 + b * b * r1) * rcp64(pn);
     };
     double alpha_lower = 0.0;
-    if (full_rank) { double ph, dp; phi_fn(0.0, ph, dp); alpha_lower = -ph / dp; }
+    if (full_rank) { double ph, dp; phi_fn(0.0, ph, dp); alpha_lower = -ph * rcp64(dp); }
     double al = alpha;
-    if (!full_rank && al == 0.0) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+    if (!full_rank && al == 0.0) al = fmax(0.001 * alpha_upper, sqrt64(alpha_lower * alpha_upper));
     for (int it = 0; it < 10; ++it) {
-        if (al < alpha_lower || al > alpha_upper) al = fmax(0.001 * alpha_upper, sqrt(alpha_lower * alpha_upper));
+        if (al < alpha_lower || al > alpha_upper) al = fmax(0.001 * alpha_upper, sqrt64(alpha_lower * alpha_upper));
         double ph, dp; phi_fn(al, ph, dp);
         if (ph < 0) alpha_upper = al;
-        double ratio = ph / dp;
+        double ratio = ph * rcp64(dp);
         alpha_lower = fmax(alpha_lower, al - ratio);
-        al -= (ph + Delta) * ratio / Delta;
+        al -= (ph + Delta) * ratio * rDelta;
         if (fabs(ph) < 0.01 * Delta) break;
     }
-    double a = suf0 / (s0s + al), b = suf1 / (s1s + al);
+    double a = suf0 * rcp64(s0s + al), b = suf1 * rcp64(s1s + al);
     p[0] = -(d.V[0][0] * a + d.V[0][1] * b);
     p[1] = -(d.V[1][0] * a + d.V[1][1] * b);
-    double sc = Delta / sqrt(p[0] * p[0] + p[1] * p[1]);
+    double sc = Delta * rcp64(sqrt64(p[0] * p[0] + p[1] * p[1]));
     p[0] *= sc; p[1] *= sc;
     alpha = al;
 }
@@ -629,10 +655,6 @@ __device__ __forceinline__ void pair_batch(const PairProblem& pb, const double x
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
         for (int i = 0; i < 3; ++i) w[i] = k ? pb.P[1][i] : pb.P[0][i];
         pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg);
-#if defined(MISTI_ABLATE) && MISTI_ABLATE == 11
-        { double w2[3] = {w[0] * 0.5, w[1] * 0.25, w[2] * 0.125}; Diag d2; pair_expv(l0, l1, pb.mu0, pb.mu1, w2, q, neg, ok, d2);
-          asm volatile("" :: "v"(w2[0]), "v"(w2[1]), "v"(w2[2])); }
-#endif
         res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
@@ -654,11 +676,7 @@ __device__ __forceinline__ void pair_batch(const PairProblem& pb, const double x
     const double fb0 = gbcast<GROUP>(res, 0), fb1 = gbcast<GROUP>(res, 1);
     const double fa0 = gbcast<GROUP>(res, 2), fa1 = gbcast<GROUP>(res, 3);
     const double fc0 = gbcast<GROUP>(res, 4), fc1 = gbcast<GROUP>(res, 5);
-#if defined(MISTI_ABLATE) && MISTI_ABLATE == 12
-    { double z0 = gbcast<GROUP>(res * 0.5, 0), z1 = gbcast<GROUP>(res * 0.5, 1), z2 = gbcast<GROUP>(res * 0.5, 2), z3 = gbcast<GROUP>(res * 0.5, 3), z4 = gbcast<GROUP>(res * 0.5, 4), z5 = gbcast<GROUP>(res * 0.5, 5);
-      asm volatile("" :: "v"(z0), "v"(z1), "v"(z2), "v"(z3), "v"(z4), "v"(z5)); }
-#endif
-    const double r0 = 1.0 / dx0, r1 = 1.0 / dx1;
+    const double r0 = rcp64(dx0), r1 = rcp64(dx1);
     f[0] = fb0; f[1] = fb1;
     J[0][0] = (fa0 - fb0) * r0; J[1][0] = (fa1 - fb1) * r0;
     J[0][1] = (fc0 - fb0) * r1; J[1][1] = (fc1 - fb1) * r1;
@@ -669,13 +687,13 @@ __device__ __forceinline__ void pair_batch(const PairProblem& pb, const double x
 // full rank and the step lies in the trust region (solve_lsq_trust_region, common.py:116-125),
 // otherwise the regularised step from the SVD.  Returns the predicted reduction.
 __device__ __forceinline__ double next_step(const double J[2][2], const double f[2], const double g[2], double Delta, double& alpha,
-                                            Svd2& sv, bool& have_sv, double p[2]) {
+                                            Svd2& sv, bool& have_sv, double p[2], int& lm) {
     const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
     const double F = (J[0][0] * J[0][0] + J[0][1] * J[0][1]) + (J[1][0] * J[1][0] + J[1][1] * J[1][1]);
     bool done = false;
     // s_max^2 <= F <= 2 s_max^2 and s_min = |det| / s_max: full rank (s_min > 2 eps s_max) is certain if |det| > 2 eps F
     if (fabs(det) > 2.0 * LSQ_EPS * 2.0 * F) {
-        const double rd = 1.0 / det;
+        const double rd = rcp64(det);
         const double p0 = -(J[1][1] * f[0] - J[0][1] * f[1]) * rd;
         const double p1 = -(J[0][0] * f[1] - J[1][0] * f[0]) * rd;
         if (p0 * p0 + p1 * p1 <= Delta * Delta) { p[0] = p0; p[1] = p1; alpha = 0.0; done = true; }
@@ -683,6 +701,7 @@ __device__ __forceinline__ double next_step(const double J[2][2], const double f
     if (!done) {
         if (!have_sv) { sv = svd_mx2<2>(J, f); have_sv = true; }
         solve_tr(sv, 2, Delta, alpha, p);
+        lm += 1;
     }
     const double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
     return -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
@@ -914,28 +933,28 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
             first = false;
             nfev = 1;
             if (!finite) { status = MISTI_NUMERIC; active = false; break; }   // SciPy raises on a non-finite start
-            Delta = sqrt(xe[0] * xe[0] + xe[1] * xe[1]);
+            Delta = sqrt64(xe[0] * xe[0] + xe[1] * xe[1]);
             if (Delta == 0) Delta = 1.0;
             alpha = 0.0;
             accept = true;
         } else {
             ++nfev;
             const double sn2 = p[0] * p[0] + p[1] * p[1];
-            if (!finite) { Delta = 0.25 * sqrt(sn2); }
+            if (!finite) { Delta = 0.25 * sqrt64(sn2); }
             else {
                 const double actual = cost - cost_new;
                 double ratio;
-                if (predicted > 0) ratio = actual / predicted;
+                if (predicted > 0) ratio = actual * rcp64(predicted);
                 else if (predicted == 0 && actual == 0) ratio = 1.0;
                 else ratio = 0.0;
                 double Delta_new = Delta;                                    // update_tr_radius, common.py:222-245
-                if (ratio < 0.25) Delta_new = 0.25 * sqrt(sn2);
+                if (ratio < 0.25) Delta_new = 0.25 * sqrt64(sn2);
                 else if (ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) Delta_new = 2.0 * Delta;
                 const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;  // check_termination, common.py:705-717
-                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt(x[0] * x[0] + x[1] * x[1]));
+                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt64(x[0] * x[0] + x[1] * x[1]));
                 const bool x_ok = sn2 < lim * lim;
                 term = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0;
-                if (term == 0) { if (alpha != 0.0) alpha *= Delta / Delta_new; Delta = Delta_new; }
+                if (term == 0) { if (alpha != 0.0) alpha *= Delta * rcp64(Delta_new); Delta = Delta_new; }
                 accept = actual > 0;
             }
         }
@@ -953,11 +972,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
             if (g_norm < LSQ_GTOL || nfev >= max_nfev || !(g_norm < INFINITY)) done = true;
         } else if (nfev >= max_nfev) done = true;
         if (!done) {
-#if defined(MISTI_ABLATE) && MISTI_ABLATE == 13
-            { double a2 = alpha, p2[2]; Svd2 s2; bool h2 = false; double f2[2] = {f[0] * 0.5, f[1] * 0.5};
-              double pr2 = next_step(J, f2, g, Delta, a2, s2, h2, p2); asm volatile("" :: "v"(pr2), "v"(p2[0]), "v"(p2[1])); }
-#endif
-            predicted = next_step(J, f, g, Delta, alpha, sv, have_sv, p);
+            predicted = next_step(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm);
             xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
         } else {
             dg.max_nfev = nfev > dg.max_nfev ? nfev : dg.max_nfev;
@@ -973,7 +988,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
             cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
             cb.fail_status[slot] = status;
             double* r = cb.work + slot * 6;
-            r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = 0.0;
+            r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = dg.lm;
 #ifdef MISTI_STAMP
             r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
 #endif
@@ -1176,8 +1191,10 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                 double p = eq * x, ii = 0.0;
                 double accp = p, acci = 0.0;
                 double b = eq, bprev = 1.0;
-                for (int k = 1; k < INV_TABLE; ++k) {
-                    double inv = c_inv[k];
+                double inv_next = c_inv[1];
+                for (int k = 1; k < INV_TABLE - 1; ++k) {
+                    const double inv = inv_next;
+                    inv_next = c_inv[k + 1];
                     xbuf[lane] = p;
                     lds_fence();
                     double r0 = xbuf[srcl[0]], r1 = xbuf[srcl[1]], r2 = xbuf[srcl[2]], r3 = xbuf[srcl[3]];

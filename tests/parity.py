@@ -52,7 +52,8 @@ def determined(out):
 
 def loose_rtol(out):
     k = out.get("sens")
-    return 1e-2 if k is None else min(1e-2, max(LLK_RTOL, 100.0 * k * PERTURB))
+    # three perturbations sample the (discrete, flip-driven) indeterminacy only coarsely: allow 1000 x
+    return 1e-2 if k is None else min(1e-2, max(LLK_RTOL, 1000.0 * k * PERTURB))
 
 
 def engine_args(case_in):
