@@ -156,6 +156,14 @@ int misti_eval_batch_dev(misti_ctx* ctx, int64_t n_cand,
 int misti_llk_dev(misti_ctx* ctx, int64_t n_cand, const double* d_jafs, const int32_t* d_status,
                   int64_t n_rep, const double* d_jsfs, double* d_llk);
 
+/* Diagnostic of the last batch evaluated on this context (either form): per candidate the
+ * largest corrected rate x interval length before smoothing (NaN where the candidate has no
+ * value, 0 with MISTI_TRUE_EPS).  From ~5 upwards the correction's residual is nearly flat in
+ * that rate: SciPy's solver in the reference then stops at a noise-dependent "runaway" rate and
+ * the reference's own log-likelihood is not determined to 1e-9.
+ * Copies n_cand doubles to HOST memory and synchronises the stream. */
+int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
+
 /* ---- measurement ----------------------------------------------------------- */
 /* When enabled, every kernel launch of this context is bracketed by HIP events
  * on its stream.  misti_kernel_times returns the accumulated device time (ms)

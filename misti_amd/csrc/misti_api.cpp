@@ -69,6 +69,8 @@ struct misti_ctx {
     DevBuf consts;                      // llh_const per replicate
     DevBuf ws_jafs, ws_status;          // spectra / status when the caller passes NULL
     DevBuf ws_order;                    // dispatch order (heaviest candidates first)
+    DevBuf ws_diag;                     // per candidate: largest corrected rate x interval length of the last batch
+    int64_t diag_n = 0;
     DevBuf ws_chain_f64, ws_chain_i32, ws_scratch, ws_temp;   // chain buffers (kernel 1 -> kernel 2), discovery scratch
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool timing = false;
@@ -201,7 +203,9 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     if (int r = record_begin(c, 1, &a, &b)) return r;
-    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->stream));
+    HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
+    c->diag_n = n_cand;
+    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(), c->stream));
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0) {
@@ -337,7 +341,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->st_split, &c->st_params, &c->st_jsfs,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->ws_diag, &c->st_split, &c->st_params, &c->st_jsfs,
                     &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     for (int w = 0; w < 3; ++w)
@@ -421,6 +425,17 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
     if (lc) HIP_TRY(hipMemcpyAsync(lc, c->st_lc.p, lc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (pr) HIP_TRY(hipMemcpyAsync(pr, c->st_pr.p, pr_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, c->st_status.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int misti_last_diag(misti_ctx* c, int64_t n_cand, double* max_rate_x_len) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (!max_rate_x_len) return fail(MISTI_E_ARG, "output is NULL");
+    if (n_cand != c->diag_n) return fail(MISTI_E_ARG, "the last batch had %lld candidates, not %lld", (long long)c->diag_n, (long long)n_cand);
+    if (n_cand == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(max_rate_x_len, c->ws_diag.p, (size_t)n_cand * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -1006,7 +1006,7 @@ template <bool CPFIT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
-                     double* __restrict__ jafs_out, int32_t* __restrict__ status_out) {
+                     double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out) {
     extern __shared__ double lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -1049,7 +1049,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         }
     }
     if (status != MISTI_OK) {
-        if (lane == 0) status_out[cand] = status;
+        if (lane == 0) { status_out[cand] = status; if (diag_out) diag_out[cand] = NAN; }
         if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
         if (lc_o)                            // partial rates (up to the failing interval) for diagnostics
             for (int i = lane; i < 2 * lc_rows; i += 64) {
@@ -1063,6 +1063,15 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         lcb[i] = (t < nfull) ? lc_ch[i] : (t == nfull && G.ins >= 0) ? cb.tail_lc[2 * cand + (i & 1)] : 0.0;
     }
     lds_fence();
+    {
+        // diagnostic: largest corrected rate x interval length before smoothing.  From ~5 upwards the
+        // correction's residual is nearly flat in that rate and the reference's own value is not
+        // determined to 1e-9; callers can tell such candidates apart.
+        double mx = 0.0;
+        for (int t = lane; t < G.split; t += 64) { double T = G.T(t); mx = fmax(mx, fmax(lcb[2 * t], lcb[2 * t + 1]) * T); }
+        for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+        if (diag_out && lane == 0) diag_out[cand] = (m.flags & MISTI_TRUE_EPS) ? 0.0 : mx;
+    }
     {
         // ---- post-split rates (:355-376); nc is a probability used as a log ----
         const double* stt = (G.ins >= 0) ? cb.tail_state + 6 * cand : tr_ch + 6 * nfull;    // pair state at the split
@@ -1527,15 +1536,15 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 }
 
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, hipStream_t stream) {
+                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (m.flags & MISTI_CPFIT)
         hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag);
     else
         hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag);
     return hipGetLastError();
 }
 

@@ -46,10 +46,11 @@ class ModelError(SystemExit):
 class BatchResult:
     """Outputs of one batch: ``llk[C][R]``, ``jafs[C][7]``, ``status[C]`` and, if
     requested, ``lc[C][numT+1][2]`` and ``pr[C][numT+2][6]``."""
-    __slots__ = ("llk", "jafs", "status", "lc", "pr")
+    __slots__ = ("llk", "jafs", "status", "lc", "pr", "runaway")
 
-    def __init__(self, llk, jafs, status, lc=None, pr=None):
+    def __init__(self, llk, jafs, status, lc=None, pr=None, runaway=None):
         self.llk, self.jafs, self.status, self.lc, self.pr = llk, jafs, status, lc, pr
+        self.runaway = runaway      # largest corrected rate x interval length (>= ~5: reference-indeterminate)
 
     @property
     def fraction_failed(self):
@@ -140,7 +141,13 @@ class Engine:
         ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
         _lib.check(self._lib.misti_eval_batch(self._ctx, n, ptr(split), ptr(par), R, ptr(rows), ptr(llk), ptr(jafs),
                                               ptr(lc), ptr(pr), ptr(status)))
-        return BatchResult(llk, jafs, status, lc, pr)
+        return BatchResult(llk, jafs, status, lc, pr, self.last_diag(n) if n else np.zeros(0))
+
+    def last_diag(self, n_cand):
+        """Largest corrected rate x interval length per candidate of the last batch (misti_last_diag)."""
+        out = np.empty(int(n_cand))
+        _lib.check(self._lib.misti_last_diag(self._ctx, int(n_cand), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     # -- device-buffer evaluation (torch tensors on this device) ------------------
     def use_stream(self, stream_handle):
@@ -354,6 +361,10 @@ class MigrationInference:
             # non-finite intermediate / stiff interval: the candidate has no value here
             print("MigrationInference: " + STATUS_TEXT.get(self.status, "status %d" % self.status))
             return -np.inf
+        self.runaway = float(res.runaway[0])
+        if self.runaway >= 5.0 and self.enableOutput:
+            print("MigrationInference: corrected rate x interval length reaches %.3g - the lambda-correction ran into its "
+                  "flat regime; the reference's value for such a candidate is not determined to 1e-9" % self.runaway)
         self.lc = [[float(a), float(b)] for a, b in res.lc[0][: self.numT]]
         self.Pr = [[[float(r[0]), float(r[1])], [float(r[2]), float(r[3])], [float(r[4]), float(r[5])]]
                    for r in res.pr[0][: self.splitT + 1]]

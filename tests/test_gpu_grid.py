@@ -48,6 +48,11 @@ def test_grid_sample_against_oracle(cfg2):
         else:
             assert err <= 1e-3 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0], run[k])
     assert n_reg >= 60 and n_out <= max(1, n_reg // 100)
+    # the engine's own diagnostic agrees with the oracle's measure of the same quantity
+    ok = (o_st == 0)
+    both_small = (run[ok] < 4.0) & (res.runaway[idx][ok] < 4.0)
+    both_big = (run[ok] > 6.0) & (res.runaway[idx][ok] > 6.0)
+    assert (both_small | both_big | ((run[ok] >= 4.0) & (run[ok] <= 6.0))).mean() > 0.98
 
 
 def test_spectrum_is_a_distribution(cfg2):
