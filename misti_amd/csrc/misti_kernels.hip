@@ -691,8 +691,20 @@ __device__ __forceinline__ double next_step(const double J[2][2], const double f
     const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
     const double F = (J[0][0] * J[0][0] + J[0][1] * J[0][1]) + (J[1][0] * J[1][0] + J[1][1] * J[1][1]);
     bool done = false;
+    // A structurally decoupled rate (Jacobian column exactly zero, see pair_expv): J has rank one,
+    // solve_lsq_trust_region takes its regularised branch and ALWAYS rescales the step to the
+    // trust radius (common.py:160-164), so the step is (0, -sign(g1) Delta) whatever alpha the
+    // secular iteration ends with - and alpha is only a starting guess for the next call.
+    const bool z0 = J[0][0] == 0.0 && J[1][0] == 0.0, z1 = J[0][1] == 0.0 && J[1][1] == 0.0;
+    if (z0 != z1) {
+        const int k = z0 ? 1 : 0;
+        p[1 - k] = 0.0;
+        p[k] = g[k] > 0 ? -Delta : Delta;
+        alpha = 0.0;
+        done = true;
+    }
     // s_max^2 <= F <= 2 s_max^2 and s_min = |det| / s_max: full rank (s_min > 2 eps s_max) is certain if |det| > 2 eps F
-    if (fabs(det) > 2.0 * LSQ_EPS * 2.0 * F) {
+    if (!done && fabs(det) > 2.0 * LSQ_EPS * 2.0 * F) {
         const double rd = rcp64(det);
         const double p0 = -(J[1][1] * f[0] - J[0][1] * f[1]) * rd;
         const double p1 = -(J[0][0] * f[1] - J[1][0] * f[0]) * rd;
