@@ -146,6 +146,25 @@ struct Model {
 // count is wave-uniform (bound from the largest q in the wave).
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
 struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0; };
+// K terms of the Taylor series of exp(M) v for the pair generator, fully unrolled.
+template <int K>
+__device__ __forceinline__ void taylor3(double d0, double d1, double d2, double mu0, double mu1, double v[3], Diag& dg) {
+    double p0 = v[0], p1 = v[1], p2 = v[2];
+    double a0 = p0, a1 = p1, a2 = p2;
+    const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        const double inv = 1.0 / (double)k;          // a literal after unrolling
+        const double t0 = (mu1 * p2 - d0 * p0) * inv;
+        const double t1 = (mu0 * p2 - d1 * p1) * inv;
+        const double t2 = ((twomu0 * p0 + twomu1 * p1) - d2 * p2) * inv;
+        p0 = t0; p1 = t1; p2 = t2;
+        a0 += p0; a1 += p1; a2 += p2;
+    }
+    dg.terms += K;
+    v[0] = a0; v[1] = a1; v[2] = a2;
+}
+
 // q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
 // base point and both forward-difference points).  M = N - q I with N >= 0.  When a state is
 // numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway rate
@@ -191,27 +210,16 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         return;
     }
     if (2.0 * nbmax <= 0.5) {
-        // small norm (the usual case: rate x interval length << 1): plain Taylor series of exp(M) v.
-        // No shift, no exp(); cancellation is bounded by e^0.5 ulp, and a decoupled component again
-        // sees identical arithmetic in every forward-difference lane.
-        double p0 = v[0], p1 = v[1], p2 = v[2];
-        double a0 = p0, a1 = p1, a2 = p2;
-        double b = 1.0;
-        const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
-        double inv_next = c_inv[1];                  // reciprocal of the NEXT term is fetched one term ahead:
-        for (int k = 1; k < 40; ++k) {               // the scalar-cache round trip would otherwise stall every term
-            const double inv = inv_next;
-            inv_next = c_inv[k + 1];
-            const double t0 = (mu1 * p2 - d0 * p0) * inv;
-            const double t1 = (mu0 * p2 - d1 * p1) * inv;
-            const double t2 = ((twomu0 * p0 + twomu1 * p1) - d2 * p2) * inv;
-            p0 = t0; p1 = t1; p2 = t2;
-            a0 += p0; a1 += p1; a2 += p2;
-            b *= 2.0 * nbmax * inv;              // ||M||_1 <= 2 (q + neg)
-            dg.terms += 1;
-            if (b < 1e-19) break;
-        }
-        v[0] = a0; v[1] = a1; v[2] = a2;
+        // small norm (the usual case: rate x interval length << 1): plain Taylor series of exp(M) v,
+        // straight-line code with a degree fixed by the norm class ((2 nb)^K / K! < 1e-19) and literal
+        // reciprocals.  No shift, no exp(); cancellation is bounded by e^0.5 ulp, and a decoupled
+        // component again sees identical arithmetic in every forward-difference lane.
+        const double nn = 2.0 * nbmax;                // >= ||M||_1
+        if (nn <= 0.01) taylor3<8>(d0, d1, d2, mu0, mu1, v, dg);
+        else if (nn <= 0.04) taylor3<10>(d0, d1, d2, mu0, mu1, v, dg);
+        else if (nn <= 0.12) taylor3<12>(d0, d1, d2, mu0, mu1, v, dg);
+        else if (nn <= 0.25) taylor3<14>(d0, d1, d2, mu0, mu1, v, dg);
+        else taylor3<17>(d0, d1, d2, mu0, mu1, v, dg);
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
