@@ -209,17 +209,19 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
-    if (2.0 * nbmax <= 0.5) {
+    if (2.0 * nbmax <= 2.0) {
         // small norm (the usual case: rate x interval length << 1): plain Taylor series of exp(M) v,
         // straight-line code with a degree fixed by the norm class ((2 nb)^K / K! < 1e-19) and literal
-        // reciprocals.  No shift, no exp(); cancellation is bounded by e^0.5 ulp, and a decoupled
+        // reciprocals.  No shift, no exp(); cancellation is bounded by e^2 ulp, and a decoupled
         // component again sees identical arithmetic in every forward-difference lane.
         const double nn = 2.0 * nbmax;                // >= ||M||_1
         if (nn <= 0.01) taylor3<8>(d0, d1, d2, mu0, mu1, v, dg);
         else if (nn <= 0.04) taylor3<10>(d0, d1, d2, mu0, mu1, v, dg);
         else if (nn <= 0.12) taylor3<12>(d0, d1, d2, mu0, mu1, v, dg);
         else if (nn <= 0.25) taylor3<14>(d0, d1, d2, mu0, mu1, v, dg);
-        else taylor3<17>(d0, d1, d2, mu0, mu1, v, dg);
+        else if (nn <= 0.5) taylor3<17>(d0, d1, d2, mu0, mu1, v, dg);
+        else if (nn <= 1.0) taylor3<21>(d0, d1, d2, mu0, mu1, v, dg);
+        else taylor3<27>(d0, d1, d2, mu0, mu1, v, dg);
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
