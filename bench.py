@@ -56,7 +56,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=16,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
-    ap.add_argument("--no-serial", action="store_true", help="skip the extra strictly-serial (1 stream) timing")
     return ap.parse_args()
 
 
