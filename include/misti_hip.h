@@ -164,6 +164,29 @@ int misti_llk_dev(misti_ctx* ctx, int64_t n_cand, const double* d_jafs, const in
  * Copies n_cand doubles to HOST memory and synchronises the stream. */
 int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
 
+/* ---- forward map (data generation; TestModel route) --------------------------- */
+/* Replaces MigrationInference.CoalescentRates (MigrationInference.py:542-564) and
+ * CorrectLambda.CoalRates (CorrectLambda.py:112-122) for a batch of candidates: the
+ * model's rates are taken as the TRUE per-population rates and the rates a single-genome
+ * (PSMC) analysis would infer under the candidate's migration model are returned.
+ *   lh   [n_cand][numT+1][2]   rows below the candidate's split: -log(P[no coalescence])/T
+ *                              of that genome's pair chain; other rows: the model's rates
+ *                              (row numT is used only by a fractional split, else 0);
+ *                              NaN rows when status is not MISTI_OK / MISTI_INF_COAL
+ *   pr   [n_cand][numT+2][6] or NULL   pair-state trace as in misti_eval_batch (rows 0..split)
+ *   status [n_cand] or NULL
+ *   hold_mu  0: every interval is evaluated with its own migration rates (the model as specified;
+ *               what generating self-consistent data wants);
+ *            1: bit-for-bit the reference's behaviour - CoalescentRates never sets the migration
+ *               rates of its CorrectLambda object, so ALL intervals see what the preceding
+ *               CorrectLambdas loop left there (:324): the rates of the candidate's last
+ *               two-population interval.  Identical to 0 when migration is constant up to the split.
+ * Host-buffer and device-buffer (asynchronous on the context's stream) forms. */
+int misti_forward_rates(misti_ctx* ctx, int64_t n_cand, const double* split_time, const double* params, int hold_mu,
+                        double* lh, double* pr, int32_t* status);
+int misti_forward_rates_dev(misti_ctx* ctx, int64_t n_cand, const double* d_split_time, const double* d_params, int hold_mu,
+                            double* d_lh, double* d_pr, int32_t* d_status);
+
 /* ---- measurement ----------------------------------------------------------- */
 /* When enabled, every kernel launch of this context is bracketed by HIP events
  * on its stream.  misti_kernel_times returns the accumulated device time (ms)

@@ -59,6 +59,8 @@ SYMBOLS = {
     "misti_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_llk_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "misti_forward_rates": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_forward_rates_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_last_diag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "misti_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_kernel_times": (C.c_int, [C.c_void_p, _PD, C.POINTER(C.c_int64), C.c_int]),

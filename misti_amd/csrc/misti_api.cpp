@@ -429,6 +429,48 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
     return 0;
 }
 
+int misti_forward_rates_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int hold_mu,
+                            double* d_lh, double* d_pr, int32_t* d_status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_cand < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_cand == 0) return 0;
+    if (!d_split || !d_lh) return fail(MISTI_E_ARG, "split_time / lh is NULL");
+    if (c->dm.n_param > 0 && !d_params) return fail(MISTI_E_ARG, "params is NULL but the model has %d parameters", c->dm.n_param);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(misti::launch_forward(c->dm, n_cand, d_split, d_params, hold_mu != 0, d_lh, d_pr, d_status, c->stream));
+    return 0;
+}
+
+int misti_forward_rates(misti_ctx* c, int64_t n_cand, const double* split, const double* params, int hold_mu,
+                        double* lh, double* pr, int32_t* status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_cand < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_cand == 0) return 0;
+    if (!split || !lh) return fail(MISTI_E_ARG, "split_time / lh is NULL");
+    const int P = c->dm.n_param, numT = c->dm.numT;
+    if (P > 0 && !params) return fail(MISTI_E_ARG, "params is NULL but the model has %d parameters", P);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nc = (size_t)n_cand;
+    const size_t lh_n = nc * (size_t)(numT + 1) * 2, pr_n = nc * (size_t)(numT + 2) * 6;
+    HIP_TRY(c->st_split.reserve(nc * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->st_split.p, split, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (P > 0) {
+        HIP_TRY(c->st_params.reserve(nc * P * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(c->st_params.p, params, nc * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c->st_lc.reserve(lh_n * sizeof(double)));
+    HIP_TRY(c->st_status.reserve(nc * sizeof(int32_t)));
+    if (pr) HIP_TRY(c->st_pr.reserve(pr_n * sizeof(double)));
+    int r = misti_forward_rates_dev(c, n_cand, c->st_split.as<double>(), P > 0 ? c->st_params.as<double>() : nullptr, hold_mu,
+                                    c->st_lc.as<double>(), pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
+    if (r) return r;
+    HIP_TRY(hipMemcpyAsync(lh, c->st_lc.p, lh_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (pr) HIP_TRY(hipMemcpyAsync(pr, c->st_pr.p, pr_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, c->st_status.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int misti_last_diag(misti_ctx* c, int64_t n_cand, double* max_rate_x_len) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     if (!max_rate_x_len) return fail(MISTI_E_ARG, "output is NULL");

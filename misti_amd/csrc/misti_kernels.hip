@@ -767,6 +767,69 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
     return status;
 }
 
+// ------------------------------------------------------------ forward map ----
+// MigrationInference.CoalescentRates (MigrationInference.py:542-564) with CorrectLambda.CoalRates
+// (CorrectLambda.py:112-122): the model's own rates lh are taken as the TRUE per-population rates;
+// for every two-population interval the rate a single-genome (PSMC) analysis would see is
+// -log(P[no coalescence in the interval]) / T under the pair chain started from that genome's
+// pair-state distribution.  No solver: one 3-state exponential action per genome and interval, so
+// one thread per candidate.  Rates after the split are returned unchanged (the loop at :563 is empty).
+// hold_mu: the reference's CoalescentRates never sets the migration rates of its CorrectLambda
+// object, so every interval is evaluated with what the preceding CorrectLambdas loop left there
+// (:324) - the rates of the LAST two-population interval.  hold_mu = 1 reproduces that; 0 applies
+// each interval's own rates (the model as specified; what data generation wants).
+__global__ __launch_bounds__(64)
+void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params, int hold_mu,
+                    double* __restrict__ lh_out, double* __restrict__ pr_out, int32_t* __restrict__ status_out) {
+    const int64_t cand = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (cand >= n_cand) return;
+    Grid G;
+    const double* par = params ? params + cand * m.n_param : nullptr;
+    const int status = setup_candidate(m, split_time[cand], par, G);
+    const int rows = m.numT + 1;
+    double* lh_o = lh_out + cand * (int64_t)rows * 2;
+    double* pr_o = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
+    if (status_out) status_out[cand] = status;
+    if (pr_o) for (int i = 0; i < (m.numT + 2) * 6; ++i) pr_o[i] = 0.0;
+    if (status != MISTI_OK && status != MISTI_INF_COAL) {
+        for (int i = 0; i < 2 * rows; ++i) lh_o[i] = NAN;
+        return;
+    }
+    Model M; M.m = &m; M.par = par; M.split = G.split; M.cache();
+    PairState ps = {{{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}}};
+    Diag dg;
+    double held0 = 0.0, held1 = 0.0;
+    if (hold_mu && G.split >= 1) M.mig((G.split < G.numT ? G.split : G.numT - 1) - 1, held0, held1);
+    for (int t = 0; t < rows; ++t) {
+        double l0 = 0.0, l1 = 0.0;
+        if (t < G.numT) { l0 = G.lhk(t, 0); l1 = G.lhk(t, 1); }
+        if (t < G.split && t < G.numT - 1) {
+            double pu0, pu1, mu0, mu1;
+            M.pulse(t, pu0, pu1);
+            pulse_pairs(ps, pu0, pu1);
+            if (t == 0 && pr_o)
+                for (int j = 0; j < 6; ++j) pr_o[j] = ps.p[j & 1][j >> 1];
+            M.mig(t, mu0, mu1);
+            if (hold_mu) { mu0 = held0; mu1 = held1; }
+            const double T = G.T(t);
+            const double a0 = l0 * T, a1 = l1 * T, b0 = mu0 * T, b1 = mu1 * T;
+            const double q = fmax(fmax(2.0 * b0 + a0, 2.0 * b1 + a1), b0 + b1);
+            for (int k = 0; k < 2; ++k) {
+                double v[3] = {ps.p[k][0], ps.p[k][1], ps.p[k][2]};
+                const double before = (v[0] + v[1]) + v[2];
+                pair_expv(a0, a1, b0, b1, v, q, 0.0, true, dg);
+                const double nc = (v[0] + v[1]) + v[2];
+                const double seen = -log(nc / before) / T;
+                if (k == 0) l0 = seen; else l1 = seen;
+                ps.p[k][0] = v[0]; ps.p[k][1] = v[1]; ps.p[k][2] = v[2];
+            }
+            if (pr_o)
+                for (int j = 0; j < 6; ++j) pr_o[6 * (t + 1) + j] = ps.p[j & 1][j >> 1];
+        }
+        lh_o[2 * t] = l0; lh_o[2 * t + 1] = l1;
+    }
+}
+
 // Kernel 1: lambda correction of the two-population intervals (CorrectLambdas loop t < splitT,
 // MigrationInference.py:307-354; SolveLambdaSystem, CorrectLambda.py:266-317).
 //
@@ -1567,6 +1630,13 @@ hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* ord
     else
         hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
                            m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
+                          int32_t* status, hipStream_t stream) {
+    if (n_cand <= 0) return hipSuccess;
+    hipLaunchKernelGGL(forward_kernel, dim3((unsigned)((n_cand + 63) / 64)), dim3(64), 0, stream, m, n_cand, split, params, hold_mu, lh_out, pr_out, status);
     return hipGetLastError();
 }
 

@@ -143,6 +143,22 @@ class Engine:
                                               ptr(lc), ptr(pr), ptr(status)))
         return BatchResult(llk, jafs, status, lc, pr, self.last_diag(n) if n else np.zeros(0))
 
+    def forward_rates(self, split_time, params=None, want_pr=False, hold_mu=False):
+        """``misti_forward_rates``: the model's rates taken as the truth -> the rates a single-genome
+        analysis would see under each candidate's migration model (CoalescentRates, :542-564).
+        ``hold_mu=True`` reproduces the reference exactly (every interval evaluated with the
+        migration rates of the last two-population interval, see include/misti_hip.h).
+        Returns (lh[n][numT+1][2], pr[n][numT+2][6] or None, status[n])."""
+        split = _f64(np.atleast_1d(split_time))
+        n = split.shape[0]
+        par = _f64(params, (n, self.n_param)) if self.n_param else None
+        lh = np.empty((n, self.numT + 1, 2))
+        pr = np.empty((n, self.numT + 2, 6)) if want_pr else None
+        status = np.empty(n, dtype=np.int32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+        _lib.check(self._lib.misti_forward_rates(self._ctx, n, ptr(split), ptr(par), 1 if hold_mu else 0, ptr(lh), ptr(pr), ptr(status)))
+        return lh, pr, status
+
     def last_diag(self, n_cand):
         """Largest corrected rate x interval length per candidate of the last batch (misti_last_diag)."""
         out = np.empty(int(n_cand))
@@ -348,6 +364,7 @@ class MigrationInference:
                 self.status = 1
                 return -np.inf
         self.MapParameters(mu)
+        self._mu = [float(v) for v in mu]
         cls.CORRECTION_CALLED += 1
         res = self._engine.evaluate([self._split_in], [list(mu)] if len(mu) else None, [self._row], want_lc=True, want_pr=True)
         self.status = int(res.status[0])
@@ -371,6 +388,23 @@ class MigrationInference:
         self.JAFS = [float(v) for v in res.jafs[0]]
         self.llh = float(res.llk[0, 0])
         return self.llh
+
+    def CoalescentRates(self):                                                  # :542-564
+        """Forward map (TestModel route): ``lc`` := the current rates, ``lh`` := what PSMC would see
+        under the current migration model, ``Pr`` := the pair-state trace.  As in the reference, every
+        interval is evaluated with the migration rates of the last two-population interval (its
+        CorrectLambda object keeps them from the preceding likelihood call); for a per-interval
+        forward map use ``Engine.forward_rates``."""
+        mu = getattr(self, "_mu", None)
+        if mu is None:
+            mu = [b[3] for b in self.optMis] + [q[2] for q in self.optPus]
+        lh, pr, status = self._engine.forward_rates([self._split_in], [list(mu)] if len(mu) else None, want_pr=True, hold_mu=True)
+        for i in range(self.numT):
+            self.lc[i] = [self.lh[i][0], self.lh[i][1]]
+        for t in range(min(self.splitT, self.numT - 1)):
+            self.lh[t] = [float(lh[0][t][0]), float(lh[0][t][1])]
+        self.Pr = [[[float(r[0]), float(r[1])], [float(r[2]), float(r[3])], [float(r[4]), float(r[5])]]
+                   for r in pr[0][: self.splitT + 1]]
 
     def JAFSLikelihoodBatch(self, split_times, params=None, jsfs_rows=None, **kw):
         """Batch form without a reference counterpart: many candidates x replicates in

@@ -83,6 +83,8 @@ class InputData:
     rho: float | None = None
     sampleDateDiscr: int = 0
     Tpsmc: list = field(default_factory=list)
+    mi: list | None = None         # [[pop(1|2), start, end, rate, optimise(0|1)], ...]   (read_ms)
+    pu: list | None = None         # [[pop(1|2), interval, fraction, optimise(0|1)], ...]
 
 
 def read_psmc_file(src, rd=-1):
@@ -164,6 +166,81 @@ def merge_psmc(d1, d2, sample_date=0.0, units=None):
 
 def read_psmc(fn1, fn2, sample_date=0.0, rd=-1, units=None):
     return merge_psmc(read_psmc_file(fn1, rd), read_psmc_file(fn2, rd), sample_date, units)
+
+
+# ------------------------------------------------------- ms command line ----
+# ms options the reader understands: name -> number of values.  Everything else is skipped one
+# token at a time, exactly as the reference does (so "-t 15000", "-I 2 2 2", "-eM ..." fall
+# through harmlessly).
+_MS_ARITY = {"-n": 2, "-en": 3, "-eN": 2, "-em": 4, "-es": 3, "-ej": 3}
+
+
+def read_ms(argument_string):
+    """An ``ms``/``scrm`` command line of a two-population split model -> model inputs
+    (``migrationIO.ReadMS``, migrationIO.py:659-753; used by ``TestModel.py:88``).
+
+    Times come out as interval lengths in coalescent units (2 x the ms time differences),
+    rates as 1/size, migration bands as ``[pop, first interval, end interval, 2 x ms rate, 0]``
+    (a band ends where the next ``-em`` of the same population starts, the last one at the split),
+    ``-es t i p`` as a pulse of fraction ``1 - p`` into population ``i``.  Sizes set with ``-eN``
+    apply to both populations; from the split on, the merged-away population copies the other one.
+    Like the reference, the reader trusts the command line: ``-ej`` must name populations 1/2.
+    """
+    tok = argument_string.split(" ")
+    size_at = [{0.0: 1.0}, {0.0: 1.0}]             # per population: time -> relative size
+    band_at = [{}, {}]                             # per receiving population: time -> ms rate
+    pulse_at = {}                                  # time -> (fraction, population)
+    split_time, moved = 0, None
+    i = 0
+    while i < len(tok):
+        opt = tok[i]
+        n = _MS_ARITY.get(opt)
+        if n is None:
+            i += 1
+            continue
+        a = tok[i + 1: i + 1 + n]
+        if opt in ("-n", "-en"):
+            when, pop, size = (0.0, int(a[0]), float(a[1])) if opt == "-n" else (float(a[0]), int(a[1]), float(a[2]))
+            if pop not in (1, 2):
+                print("Population id should be 1 or 2.")
+                print(" ".join(tok[i: i + 1 + n]))
+                raise SystemExit(0)
+            size_at[pop - 1][when] = size
+        elif opt == "-eN":
+            size_at[0][float(a[0])] = size_at[1][float(a[0])] = float(a[1])
+        elif opt == "-em":
+            pop = int(a[1])
+            band_at[pop - 1][float(a[0])] = float(a[3])
+        elif opt == "-es":
+            pulse_at[float(a[0])] = (1 - float(a[2]), int(a[1]))
+        elif opt == "-ej" and int(a[1]) <= 2:
+            split_time, moved = float(a[0]), int(a[1]) - 1
+        i += 1 + n
+    if moved is None:
+        print("Populations should be merged. (-ej [time] 2 1)")
+        raise SystemExit(0)
+    knots = sorted(set(size_at[0]) | set(size_at[1]) | set(band_at[0]) | set(band_at[1]) | set(pulse_at) | {split_time})
+    index = {t: k for k, t in enumerate(knots)}
+    split = index[split_time]
+    sizes = [[0, 0] for _ in knots]
+    for k in (0, 1):
+        cur = 0
+        for j, t in enumerate(knots):
+            v = size_at[k].get(t, 0)
+            cur = v if v != 0 else cur              # a size of exactly 0 means "unchanged", as in the reference
+            sizes[j][k] = cur
+    for j in range(split, len(knots)):
+        sizes[j][moved] = sizes[j][1 - moved]
+    mis = []
+    for k in (0, 1):
+        starts = sorted(band_at[k])
+        for a, t in enumerate(starts):
+            end = index[starts[a + 1]] if a + 1 < len(starts) else split
+            mis.append([k + 1, index[t], end, 2 * band_at[k][t], 0])
+    pus = [[pop, index[t], frac, 0] for t, (frac, pop) in pulse_at.items()]
+    times = [2 * (b - a) for a, b in zip(knots[:-1], knots[1:])]
+    lambdas = [[1.0 / u, 1.0 / v] for u, v in sizes]
+    return InputData(times, lambdas, 1.0, 1.0, divergenceTime=split, mi=mis, pu=pus)
 
 
 # ---------------------------------------------------------------- JSFS ----

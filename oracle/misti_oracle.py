@@ -692,8 +692,13 @@ class OracleModel:
         return llh
 
     # -- forward map (TestModel route) -------------------------------------
-    def coalescent_rates(self):                                         # :542-564
-        """True rates ``lh`` + migration -> PSMC-like rates; overwrites self.lh."""
+    def coalescent_rates(self, hold_mu=False):                          # :542-564
+        """True rates ``lh`` + migration -> PSMC-like rates; overwrites self.lh.
+
+        The reference never calls SetMu here: its CorrectLambda object keeps the migration rates
+        of the LAST two-population interval from the preceding CorrectLambdas loop (:324) and
+        applies them to every interval.  ``hold_mu=True`` restates exactly that; the default
+        applies each interval's own rates (the model as specified)."""
         self.Pr = []
         for i in range(self.numT):
             self.lc[i] = [self.lh[i][0], self.lh[i][1]]
@@ -702,7 +707,8 @@ class OracleModel:
             p0 = _pulse_pairs(p0, self.pu[t])
             if t == 0:
                 self.Pr.append([[p0[0][0], p0[1][0]], [p0[0][1], p0[1][1]], [p0[0][2], p0[1][2]]])
-            self.cl.set_mu(self.mi[t][0], self.mi[t][1])   # NB: reference leaves mu from the last call
+            tm = self.splitT - 1 if hold_mu else t
+            self.cl.set_mu(self.mi[tm][0], self.mi[tm][1])
             self.cl.set_interval(self.lh[t], self.times[t], p0)
             self.lh[t], p0 = self.cl.coal_rates(self.lc[t])
             self.Pr.append([[p0[0][0], p0[1][0]], [p0[0][1], p0[1][1]], [p0[0][2], p0[1][2]]])

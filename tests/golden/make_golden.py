@@ -222,6 +222,44 @@ def synthetic_cases():
     return c
 
 
+MS_STRINGS = [
+    # SURVEY appendix A anchor (TestModel route)
+    ("ms_anchor", True, "4 100 -t 15000 -r 1920 30000000 -l -I 2 2 2 -n 1 10 -n 2 4.5 -em 0.0 1 2 2.0 -em 0.0 2 1 3.0 "
+                        "-eN 0.025 0.2 -ej 0.045 2 1 -eN 0.175 3 -eN 0.625 1.8 -eN 3 3.2 -eN 8 5.5"),
+    # band chaining (two -em of one population), per-population size changes, folded
+    ("ms_chain", False, "4 1 -t 100 -I 2 2 2 -n 1 1.5 -n 2 0.7 -em 0.0 1 2 1.0 -em 0.02 1 2 0.25 -em 0.01 2 1 0.5 "
+                        "-en 0.03 1 2.0 -en 0.05 2 0.4 -ej 0.11 2 1 -eN 0.4 2.5 -eN 1.5 1.0"),
+    # a pulse (-es), migration ending before the split (-em ... 0), population 1 merged into 2
+    ("ms_pulse", True, "4 1 -t 100 -I 2 2 2 -n 2 3.0 -em 0.0 2 1 1.5 -em 0.04 2 1 0 -es 0.02 1 0.8 -en 0.06 1 0.5 "
+                       "-ej 0.2 1 2 -eN 0.5 2.0 -eN 2.0 4.0"),
+    # no migration at all
+    ("ms_nomig", True, "4 1 -t 100 -I 2 2 2 -n 1 2.0 -n 2 0.5 -en 0.05 1 1.0 -ej 0.3 2 1 -eN 0.6 1.7 -eN 3.0 0.8"),
+]
+
+
+def ms_cases():
+    """ReadMS -> MigrationInference(trueEPS) -> JAFSLikelihood([]) -> CoalescentRates(): the TestModel.py route."""
+    out = []
+    for name, unfolded, text in MS_STRINGS:
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink), contextlib.redirect_stderr(sink):
+            d = migrationIO.ReadMS(text)
+            rec = {"name": name, "ms": text, "unfolded": unfolded,
+                   "times": [float(v) for v in d.times], "lambdas": [[float(a), float(b)] for a, b in d.lambdas],
+                   "divergenceTime": d.divergenceTime, "mi": [list(map(float, m)) for m in d.mi], "pu": [list(map(float, q)) for q in d.pu]}
+            m = MI.MigrationInference(list(d.times), [list(x) for x in d.lambdas], [1] * 8, d.divergenceTime,
+                                      [list(x) for x in d.mi], [list(x) for x in d.pu], unfolded=unfolded, trueEPS=True)
+            llh = m.JAFSLikelihood([])
+            rec["llh"] = float(llh)
+            rec["JAFS"] = [float(v) for v in m.JAFS]
+            rec["lc"] = [[float(a), float(b)] for a, b in m.lc]
+            m.CoalescentRates()
+            rec["forward_lh"] = [[float(a), float(b)] for a, b in m.lh]
+            rec["forward_Pr"] = [[[float(c) for c in r] for r in p] for p in m.Pr]
+        out.append(rec)
+    return out
+
+
 def dedupe(cases):
     """Store each (times, lambdas) grid once; cases refer to it by key."""
     grids = {}
@@ -257,6 +295,9 @@ def main():
     json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6",
                "grids": dedupe(s), "cases": s},
               open(os.path.join(HERE, "golden_synthetic.json"), "w"))
+    ms = ms_cases()
+    json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6", "cases": ms},
+              open(os.path.join(HERE, "golden_ms.json"), "w"))
     n_inf = sum(1 for x in a + s if x["out"]["llh"] is None)
     print("wrote %d small + %d synthetic cases (%d -inf) in %.1f s" % (len(a), len(s), n_inf, time.time() - t0))
 
