@@ -29,15 +29,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+# Lanes (HIP streams with independent batches in flight).  Measured on MI355X / ROCm 7.2: own streams map
+# one-to-one onto hardware queues up to 24 queues per process; one queue more and the driver time-slices
+# them (throughput collapses 2x).  22 lanes is the single-process peak; defaults leave room for the null
+# stream and, with several ranks, for RCCL's and torch's own streams.
+# (single rank with RCCL initialised: 18 lanes fine, 20 collapse -> 14 with several ranks, 4 queues spare)
+DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 14
+HW_QUEUES = 24
+HW_QUEUE_SLACK = 4
+
+
 def _early_streams():
     """--streams must reach the HIP runtime (hardware queue count) before it initialises."""
-    n = 16
+    n, q = DEFAULT_STREAMS, None
     for i, a in enumerate(sys.argv):
-        if a == "--streams" and i + 1 < len(sys.argv):
-            n = int(sys.argv[i + 1])
-        elif a.startswith("--streams="):
-            n = int(a.split("=", 1)[1])
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, n)))
+        for name in ("--streams", "--hw-queues"):
+            v = None
+            if a == name and i + 1 < len(sys.argv):
+                v = int(sys.argv[i + 1])
+            elif a.startswith(name + "="):
+                v = int(a.split("=", 1)[1])
+            if v is not None:
+                n, q = (v, q) if name == "--streams" else (n, v)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(q if q else max(HW_QUEUES, n + HW_QUEUE_SLACK)))
 
 
 _early_streams()
@@ -54,7 +68,9 @@ def parse():
     ap.add_argument("--workload", default="config2", help="config2 (headline) | config3 | config4 | config5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all_gather path even with one rank (rehearsal)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES (default: %d)" % HW_QUEUES)
+    ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
     return ap.parse_args()
 
@@ -82,6 +98,11 @@ def algorithmic_bytes(w, n_rep):
 
 def main():
     a = parse()
+    # stdout carries exactly one JSON line: libraries that print banners there (RCCL prints its version
+    # block on communicator creation) are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from misti_amd import workloads
@@ -97,9 +118,15 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist          # --force-dist: rehearse the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload ---------------------------------------------------------------
     spec = lambda *args: truth_spectrum(*args, device=local_rank)
@@ -111,38 +138,51 @@ def main():
     d_split = torch.as_tensor(w.split_time, dtype=torch.float64, device=dev)
     d_par = torch.as_tensor(w.params, dtype=torch.float64, device=dev).contiguous() if P else None
     d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
-    d_all = torch.empty((world * n, R), dtype=torch.float64, device=dev) if world > 1 else None
+    d_all = torch.empty((world * n, R), dtype=torch.float64, device=dev) if use_dist else None
 
-    comm_stream = torch.cuda.Stream() if world > 1 else None
+    comm_stream = torch.cuda.Stream() if use_dist else None
 
     class Lane:
-        """One engine context + its output buffers on one HIP stream."""
-        def __init__(self, stream):
-            self.stream = stream
+        """One engine context + its output buffers on one HIP stream.
+
+        A lane issues on its engine's OWN stream (hipStreamCreate inside misti_create): streams created
+        one by one map to distinct hardware queues, whereas streams handed out by torch's pool share
+        them (measured: ~11 long kernels in flight on 12 own streams against ~6 on 16 pool streams)."""
+        def __init__(self, stream=None):
             self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
-            self.eng.use_stream(stream.cuda_stream)
-            self.llk = torch.empty((n, R), dtype=torch.float64, device=dev)
+            if stream is not None:
+                self.eng.use_stream(stream.cuda_stream)
+                self.stream = stream
+            else:
+                self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
+            # two result buffers per lane: the gather of step i reads one while step i+1 fills the other
+            self.llk_bufs = [torch.empty((n, R), dtype=torch.float64, device=dev) for _ in range(2 if use_dist else 1)]
+            self.llk = self.llk_bufs[0]
             self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
             self.status = torch.empty(n, dtype=torch.int32, device=dev)
-            self.gathered = None
+            self.gathered = [None, None]
+            self.turn = 0
 
         def step(self):
-            if self.gathered is not None:                      # the previous gather of this lane still reads self.llk
-                self.stream.wait_event(self.gathered)
+            k = self.turn
+            self.turn = (k + 1) % len(self.llk_bufs)
+            self.llk = self.llk_bufs[k]
+            if self.gathered[k] is not None:                   # the gather issued two steps ago on this lane still reads this buffer
+                self.stream.wait_event(self.gathered[k])
             self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
                                   self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
-            if world > 1:
+            if use_dist:
                 # one communicator: gathers are serialised on a dedicated stream, in issue order on every rank
                 done = torch.cuda.Event()
                 done.record(self.stream)
                 comm_stream.wait_event(done)
                 with torch.cuda.stream(comm_stream):
                     dist.all_gather_into_tensor(d_all, self.llk)
-                    self.gathered = torch.cuda.Event()
-                    self.gathered.record(comm_stream)
+                    self.gathered[k] = torch.cuda.Event()
+                    self.gathered[k].record(comm_stream)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -159,17 +199,17 @@ def main():
             lanes[i % len(lanes)].step()
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
 
     n_streams = max(1, a.streams)
-    main_lanes = [Lane(torch.cuda.Stream()) for i in range(n_streams)]
+    main_lanes = [Lane() for i in range(n_streams)]
     dt = timed(main_lanes, timing=False)
     # strictly serial pass on one stream: per-kernel durations (HIP events on the launch stream) and the serial rate
-    serial = Lane(torch.cuda.current_stream())
+    serial = main_lanes[0]
     eng = serial.eng
     k_serial = max(4, min(a.steps, 16))
     keep = (a.steps, a.warmup)
@@ -245,8 +285,9 @@ def main():
                             "frac_within_1e-9": float((rel[regular] <= 1e-9).mean()) if regular.any() else None},
                 "runaway_rate_candidates": {"n": int(runaway.sum()), "max_rel": float(rel[runaway].max()) if runaway.any() else None,
                                             "note": "reference-indeterminate (corrected rate x interval length >= 5): the reference's own value is noise-driven"}}
-        print(json.dumps(out))
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -117,6 +117,9 @@ int misti_destroy(misti_ctx* ctx);
  * of the context's own; pass NULL to go back.  The stream must belong to the
  * context's device. */
 int misti_set_stream(misti_ctx* ctx, void* hip_stream);
+/* The hipStream_t the context currently issues on (its own non-blocking stream unless replaced):
+ * lets a caller order its own work or events against the batch (bench.py wraps it for RCCL). */
+int misti_get_stream(misti_ctx* ctx, void** hip_stream);
 int misti_sync(misti_ctx* ctx);
 
 /* ---- batched JAFSLikelihood ----------------------------------------------- */

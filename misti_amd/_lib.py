@@ -53,6 +53,7 @@ SYMBOLS = {
     "misti_create": (C.c_int, [C.POINTER(Model), C.c_int, C.POINTER(C.c_void_p)]),
     "misti_destroy": (C.c_int, [C.c_void_p]),
     "misti_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "misti_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "misti_sync": (C.c_int, [C.c_void_p]),
     "misti_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

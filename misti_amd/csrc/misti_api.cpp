@@ -71,6 +71,7 @@ struct misti_ctx {
     DevBuf ws_order;                    // dispatch order (heaviest candidates first)
     DevBuf ws_diag;                     // per candidate: largest corrected rate x interval length of the last batch
     int64_t diag_n = 0;
+    DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32, ws_scratch, ws_temp;   // chain buffers (kernel 1 -> kernel 2), discovery scratch
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool timing = false;
@@ -174,13 +175,15 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     size_t temp_bytes = 0;
     HIP_TRY(misti::chain_temp_bytes(n_cand, &temp_bytes));
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
-    const size_t i32_n = 1 + 6 * nc + 1;                         // n_chains, rep, len, of, fail_t, fail_status, tail_status
+    const size_t ntr = (size_t)misti::trunk_capacity(n_cand);
+    const size_t i32_n = 1 + 6 * nc + 1 + ntr;                   // n_chains, rep, len, of, fail_t, fail_status, tail_status, trunk_ok
     const size_t scratch_bytes = nc * 2 * sizeof(uint64_t) + nc * 4 * sizeof(int32_t);
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
     HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
     HIP_TRY(c->ws_scratch.reserve(scratch_bytes));
     HIP_TRY(c->ws_temp.reserve(temp_bytes + 16));
     HIP_TRY(c->ws_order.reserve(nc * sizeof(int32_t)));
+    if (ntr) HIP_TRY(c->ws_trunk.reserve(ntr * numT * misti::TRUNK_REC * sizeof(double)));
     misti::ChainBufs cb;
     {
         double* d = c->ws_chain_f64.as<double>();
@@ -192,7 +195,10 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         int32_t* q = c->ws_chain_i32.as<int32_t>();
         cb.n_chains = q; q += 2;
         cb.rep = q; q += nc; cb.len = q; q += nc; cb.of = q; q += nc;
-        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q;
+        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc;
+        cb.trunk_ok = q;
+        cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
+        cb.trunk_cap = (int64_t)ntr;
     }
     int32_t* d_order = c->ws_order.as<int32_t>();
     hipEvent_t a = nullptr, b = nullptr;
@@ -341,7 +347,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->ws_diag, &c->st_split, &c->st_params, &c->st_jsfs,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->st_split, &c->st_params, &c->st_jsfs,
                     &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     for (int w = 0; w < 3; ++w)
@@ -354,6 +360,12 @@ int misti_destroy(misti_ctx* c) {
 int misti_set_stream(misti_ctx* c, void* s) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    return 0;
+}
+
+int misti_get_stream(misti_ctx* c, void** s) {
+    if (!c || !s) return fail(MISTI_E_ARG, "ctx / output is NULL");
+    *s = static_cast<void*>(c->stream);
     return 0;
 }
 

@@ -9,5 +9,7 @@ constexpr int WAVES_PER_BLOCK = 4;    // candidates per 256-thread workgroup
 constexpr int TALBOT_N = 28;           // nodes of the Talbot contour (conjugate pairs folded: TALBOT_HALF solves)
 constexpr int TALBOT_HALF = TALBOT_N / 2;
 constexpr int INV_TABLE = 1024;         // reciprocal table for the series (also the cap on terms per series)
+constexpr int TRUNK_REC = 3 * NS2;    // doubles per trunk record: state vector | occupation integral before | from the sample date
+constexpr int TRUNK_MIN_SHARE = 8;    // the trunk runs when a chain has on average at least this many candidates
 constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
 }  // namespace misti

@@ -55,10 +55,14 @@ struct ChainBufs {
     double* tail_lc;        // [n][2] per candidate with a fractional split
     double* tail_state;     // [n][6]
     int32_t* tail_status;   // [n]
+    double* trunk;          // [trunk_cap][numT][TRUNK_REC] per chain: 44-state vector + occupation integrals before interval t
+    int32_t* trunk_ok;      // [trunk_cap] per chain: last valid record
+    int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
 };
 
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
+int64_t trunk_capacity(int64_t n_cand);
 hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream);
 hipError_t chain_temp_bytes(int64_t n, size_t* bytes);
 hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, ChainBufs cb,

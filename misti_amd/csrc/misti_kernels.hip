@@ -1083,6 +1083,210 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
     }
 }
 
+// ---- two-population propagation shared by the trunk and the candidate kernel ----
+// Row view of the 44-state generator for state `lane`, kept in registers.
+struct TwoPopRow {
+    int srcl[MAXNZ], knd[MAXNZ];
+    double mlt[MAXNZ];
+    double dc0, dc1, dc2, dc3;
+    bool live;
+    __device__ __forceinline__ void load(int lane) {
+        for (int n = 0; n < MAXNZ; ++n) { srcl[n] = c_tab.src[n][lane]; knd[n] = c_tab.kind[n][lane]; mlt[n] = (double)c_tab.mult[n][lane]; }
+        dc0 = c_tab.dcnt[0][lane]; dc1 = c_tab.dcnt[1][lane]; dc2 = c_tab.dcnt[2][lane]; dc3 = c_tab.dcnt[3][lane];
+        live = lane < NS2;
+    }
+};
+
+// AncientSampleP0 (TwoPopulations.py:246-262)
+__device__ __forceinline__ void ancient_project(double* xbuf, int lane, double& x) {
+    xbuf[lane] = x; lds_fence();
+    double nx = 0.0;
+    for (int a = 0; a < 2; ++a) if (lane == c_tab.anc_dst[a]) for (int j = 0; j < c_tab.anc_n[a]; ++j) nx += xbuf[c_tab.anc_src[a][j]];
+    lds_fence();
+    x = nx;
+}
+
+// One interval of the two-population loop (JAFSpectrum :483-502): pulse at the start of the
+// interval, then x <- exp(M T) x and the occupation integral added to w_pre / w_post.
+// lcb: this wave's (smoothed) rates in LDS.  Returns MISTI_OK / MISTI_NUMERIC / MISTI_STIFF.
+__device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevModel& m, const Model& mod, const Grid& G, const double* lcb,
+                                               double* xbuf, int lane, int t, double& x, double& w_pre, double& w_post) {
+    double pu0, pu1, mu0, mu1;
+    mod.pulse(t, pu0, pu1);
+    mod.mig(t, mu0, mu1);
+    double pr = pu0 + pu1;
+    if (pr > 0) {
+        // PulseMigration (TwoPopulations.py:361-377)
+        int from = pu0 > 0 ? 0 : 1;
+        xbuf[lane] = x; lds_fence();
+        double pw_s[5], pw_m[5];
+        pw_s[0] = pw_m[0] = 1.0;
+        for (int i = 1; i < 5; ++i) { pw_s[i] = pw_s[i - 1] * (1.0 - pr); pw_m[i] = pw_m[i - 1] * pr; }
+        double nx = 0.0;
+        int n = R.live ? c_tab.pulse_n[from][lane] : 0;
+        for (int j = 0; j < n; ++j) {
+            int ab = c_tab.pulse_ab[from][lane][j];
+            int mul = ab >> 8, a = (ab >> 4) & 15, b = ab & 15;
+            nx += xbuf[c_tab.pulse_src[from][lane][j]] * ((double)mul * pw_s[a] * pw_m[b]);
+        }
+        lds_fence();
+        x = nx;
+    }
+    double la0 = lcb[2 * t], la1 = lcb[2 * t + 1];
+    double T = G.T(t);
+    // largest total exit rate over the 44 states (4 lineages dominate)
+    double r40 = 6 * la0 + 4 * mu0, r04 = 6 * la1 + 4 * mu1;
+    double r31 = 3 * la0 + 3 * mu0 + mu1, r13 = 3 * la1 + 3 * mu1 + mu0;
+    double r22 = la0 + la1 + 2 * mu0 + 2 * mu1;
+    double q = T * fmax(fmax(r40, r04), fmax(fmax(r31, r13), r22));
+    if (!(q < 1e300)) return MISTI_NUMERIC;
+    double rate[4] = {la0, la1, mu0, mu1};
+    double cf[MAXNZ];
+    for (int n = 0; n < MAXNZ; ++n) cf[n] = R.mlt[n] * rate[R.knd[n]] * T;
+    const double dT = (R.dc0 * la0 + R.dc1 * la1 + R.dc2 * mu0 + R.dc3 * mu1) * T;   // exit rate x T of this state
+    double wint = 0.0;
+    if (q <= Q_SWITCH) {
+        // uniformisation: M T = N - q I, p_{k+1} = N p_k/(k+1), i_{k+1} = (T p_k + q i_k)/(k+1)
+        const double dg = q - dT;
+        const double eq = exp(-q);
+        double p = eq * x, ii = 0.0;
+        double accp = p, acci = 0.0;
+        double b = eq, bprev = 1.0;
+        double inv_next = c_inv[1];
+        for (int k = 1; k < INV_TABLE - 1; ++k) {
+            const double inv = inv_next;
+            inv_next = c_inv[k + 1];
+            xbuf[lane] = p;
+            lds_fence();
+            double r0 = xbuf[R.srcl[0]], r1 = xbuf[R.srcl[1]], r2 = xbuf[R.srcl[2]], r3 = xbuf[R.srcl[3]];
+            lds_fence();
+            double pn = (dg * p + ((cf[0] * r0 + cf[1] * r1) + (cf[2] * r2 + cf[3] * r3))) * inv;
+            ii = (T * p + q * ii) * inv;
+            p = pn;
+            accp += p; acci += ii;
+            bprev = b;
+            b *= q * inv;
+            if (bprev < 1e-19 && (double)k > q) break;
+        }
+        x = accp; wint = acci;
+    } else {
+        // Talbot contour, conjugate pairs folded: f = 2 Re sum_{k upper} (-c_k) (z_k - M T)^-1 x
+        double accp = 0.0, acci = 0.0;
+        bool stalled = false;
+        for (int nd = 0; nd < TALBOT_HALF; ++nd) {
+            const double zr = c_tab.tal_zr[nd], zi = c_tab.tal_zi[nd], cr = c_tab.tal_cr[nd], ci = c_tab.tal_ci[nd];
+            const double ar = zr + dT, ai = zi;
+            const double den = 1.0 / (ar * ar + ai * ai);
+            const double ir = ar * den, im = -ai * den;              // 1 / (z + D_i)
+            double xr = x * ir, xi = x * im;
+            int it = 0;
+            for (; it < JACOBI_MAX; ++it) {
+                xbuf[lane] = xr; xbuf[64 + lane] = xi;
+                lds_fence();
+                double sr = x + ((cf[0] * xbuf[R.srcl[0]] + cf[1] * xbuf[R.srcl[1]]) + (cf[2] * xbuf[R.srcl[2]] + cf[3] * xbuf[R.srcl[3]]));
+                double si = (cf[0] * xbuf[64 + R.srcl[0]] + cf[1] * xbuf[64 + R.srcl[1]]) + (cf[2] * xbuf[64 + R.srcl[2]] + cf[3] * xbuf[64 + R.srcl[3]]);
+                lds_fence();
+                double nr = sr * ir - si * im, ni = sr * im + si * ir;
+                bool moving = (fabs(nr - xr) + fabs(ni - xi)) > 4e-16 * (fabs(nr) + fabs(ni)) + 1e-300;
+                xr = nr; xi = ni;
+                if (!__any(moving)) break;
+            }
+            if (it >= JACOBI_MAX) stalled = true;
+            const double wr = -(cr * xr - ci * xi), wi = -(cr * xi + ci * xr);
+            const double zz = 1.0 / (zr * zr + zi * zi);
+            const double gr = T * zr * zz, gi = -T * zi * zz;        // T / z
+            accp += 2.0 * wr;
+            acci += 2.0 * (wr * gr - wi * gi);
+        }
+        if (stalled) return MISTI_STIFF;
+        x = accp; wint = acci;
+    }
+    if (t < m.sample_date) w_pre += wint; else w_post += wint;
+    return MISTI_OK;
+}
+
+// Smooth (:380-405) on a wave's rates in LDS: time-weighted mean of lc over runs of constant lh,
+// t < bound; a run is cut at `bound` (the candidate's split index).
+__device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, double* lcb, int lane, int bound) {
+    double sm[SMOOTH_REPS][2];   // intervals rep*64+lane, both genomes
+#pragma unroll
+    for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
+        int t = rep * 64 + lane;
+        for (int k = 0; k < 2; ++k) {
+            double v = 0.0;
+            if (t < bound) {
+                int a = m.run_start[k * m.numT + t];
+                int b = m.run_end[k * m.numT + t];
+                if (b > bound) b = bound;
+                double acc = 0.0, tt = 0.0;
+                for (int j = a; j < b; ++j) { double Tj = G.T(j); acc += lcb[2 * j + k] * Tj; tt += Tj; }
+                v = acc / tt;
+            }
+            sm[rep][k] = v;
+        }
+    }
+    lds_fence();
+#pragma unroll
+    for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
+        int t = rep * 64 + lane;
+        if (t < bound) { lcb[2 * t] = sm[rep][0]; lcb[2 * t + 1] = sm[rep][1]; }
+    }
+    lds_fence();
+}
+
+// Trunk kernel.  Candidates of one chain (same parameters, different split) propagate the 44-state
+// chain through the SAME intervals with the SAME rates up to the smoothing run their split cuts:
+// the rates of interval t, the migration rates and the pulses do not depend on the split as long
+// as every smoothing run touching [0, t] ends at or before it.  One wavefront per chain walks the
+// chain's intervals once and stores, before each interval t, the state vector and both occupation
+// integrals (3 x 44 doubles); a candidate then starts from the record of the first interval whose
+// run its split cuts (t_own in spectrum_kernel) and adds only its own 0-5 intervals - on a
+// split x rate grid ~14x less propagation work.  The arithmetic per interval is the same code
+// (twopop_interval) on the same inputs, so a candidate's result is bit-identical with or without
+// the trunk (tests/test_gpu_grid.py::test_trunk_is_bit_identical).
+// Active only when sharing pays: n_chains * TRUNK_MIN_SHARE <= n_cand (decided on the device, the
+// chain count never visits the host).
+__device__ __forceinline__ bool trunk_active(const ChainBufs& cb, int64_t n_cand) {
+    const int64_t nch = cb.n_chains[0];
+    return cb.trunk_cap > 0 && nch <= cb.trunk_cap && nch * TRUNK_MIN_SHARE <= n_cand;
+}
+
+__global__ __launch_bounds__(64)
+void trunk_kernel(DevModel m, int64_t n_cand, const double* __restrict__ params, ChainBufs cb) {
+    extern __shared__ double lds[];
+    const int lane = lane_id();
+    const int64_t ch = blockIdx.x;
+    if (!trunk_active(cb, n_cand) || ch >= cb.n_chains[0]) return;
+    double* xbuf = lds;
+    double* lcb = lds + 128;
+    const int ft = cb.fail_t[ch];
+    int Lt = cb.len[ch];
+    if (ft < Lt) Lt = ft;                                   // members beyond the failing interval have no value anyway
+    const double* par = params ? params + (int64_t)cb.rep[ch] * m.n_param : nullptr;
+    Grid G;
+    G.times = m.times; G.lh = m.lh; G.numT0 = m.numT; G.numT = m.numT; G.split = Lt; G.ins = -1; G.frac = 0.0;
+    Model mod{&m, par, Lt, {0, 0, 0, 0}};
+    mod.cache();
+    const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
+    for (int i = lane; i < 2 * (m.numT + 1); i += 64) lcb[i] = ((i >> 1) < Lt) ? lc_ch[i] : 0.0;
+    lds_fence();
+    if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, Lt);
+    TwoPopRow R;
+    R.load(lane);
+    double x = (lane == 2) ? 1.0 : 0.0;
+    double w_pre = 0.0, w_post = 0.0;
+    double* rec = cb.trunk + ch * (int64_t)m.numT * TRUNK_REC;
+    int ok = 0;
+    for (int t = 0; t < m.numT; ++t) {
+        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = x; r[NS2 + lane] = w_pre; r[2 * NS2 + lane] = w_post; }
+        ok = t;
+        if (t >= Lt) break;
+        if (t == m.sample_date) ancient_project(xbuf, lane, x);
+        if (twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post) != MISTI_OK) break;
+    }
+    if (lane == 0) cb.trunk_ok[ch] = ok;
+}
+
 // Kernel 2: post-split rates (:355-376), Smooth (:380-405) and the expected joint spectrum
 // (JAFSpectrum, :467-540).  One wavefront per candidate; lane = interval in the prologue,
 // lane = state of the 44-state chain afterwards.
@@ -1194,32 +1398,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         }
         lds_fence();
         // ---- Smooth (:380-405): time-weighted mean of lc over runs of constant lh, t < split
-        if (m.flags & MISTI_SMOOTH) {
-            double sm[SMOOTH_REPS][2];   // intervals rep*64+lane, both genomes
-#pragma unroll
-            for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
-                int t = rep * 64 + lane;
-                for (int k = 0; k < 2; ++k) {
-                    double v = 0.0;
-                    if (t < G.split) {
-                        int a = m.run_start[k * m.numT + t];
-                        int b = m.run_end[k * m.numT + t];
-                        if (b > G.split) b = G.split;
-                        double acc = 0.0, tt = 0.0;
-                        for (int j = a; j < b; ++j) { double Tj = G.T(j); acc += lcb[2 * j + k] * Tj; tt += Tj; }
-                        v = acc / tt;
-                    }
-                    sm[rep][k] = v;
-                }
-            }
-            lds_fence();
-#pragma unroll
-            for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
-                int t = rep * 64 + lane;
-                if (t < G.split) { lcb[2 * t] = sm[rep][0]; lcb[2 * t + 1] = sm[rep][1]; }
-            }
-            lds_fence();
-        }
+        if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, G.split);
         for (int i = lane; i < 2 * G.numT; i += 64) { double v = lcb[i]; if (!(v == v)) status = MISTI_NUMERIC; }
         status = __any(status != MISTI_OK) ? MISTI_NUMERIC : MISTI_OK;
         if (lc_o) for (int i = lane; i < 2 * lc_rows; i += 64) lc_o[i] = (i < 2 * G.numT) ? lcb[i] : 0.0;
@@ -1228,113 +1407,33 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
 
     if (status == MISTI_OK) {
         // ---- expected spectrum, two-population part (:467-506) ----------------
-        int srcl[MAXNZ], knd[MAXNZ]; double mlt[MAXNZ];
-        for (int n = 0; n < MAXNZ; ++n) { srcl[n] = c_tab.src[n][lane]; knd[n] = c_tab.kind[n][lane]; mlt[n] = (double)c_tab.mult[n][lane]; }
-        double dc0 = c_tab.dcnt[0][lane], dc1 = c_tab.dcnt[1][lane], dc2 = c_tab.dcnt[2][lane], dc3 = c_tab.dcnt[3][lane];
-        const bool live = lane < NS2;
+        TwoPopRow R;
+        R.load(lane);
+        const bool live = R.live;
         double x = (lane == 2) ? 1.0 : 0.0;
         double w_pre = 0.0, w_post = 0.0;          // occupation integrals before / from the sample date
-        for (int t = 0; t <= G.split && t < G.numT; ++t) {
-            if (t == m.sample_date) {
-                // AncientSampleP0 (TwoPopulations.py:246-262)
-                xbuf[lane] = x; lds_fence();
-                double nx = 0.0;
-                for (int a = 0; a < 2; ++a) if (lane == c_tab.anc_dst[a]) for (int j = 0; j < c_tab.anc_n[a]; ++j) nx += xbuf[c_tab.anc_src[a][j]];
-                lds_fence();
-                x = nx;
+        int t0 = 0;
+        if (trunk_active(cb, n_cand)) {
+            // first interval whose rates depend on this candidate's split: the start of the smoothing
+            // run (of either genome) that the split cuts; the shortened interval of a fractional split
+            int t_own = nfull;
+            if (m.flags & MISTI_SMOOTH) {
+                if (G.ins >= 0) {
+                    t_own = min(m.run_start[G.ins], m.run_start[m.numT + G.ins]);
+                } else if (G.split > 0) {
+                    for (int k = 0; k < 2; ++k)
+                        if (m.run_end[k * m.numT + G.split - 1] > G.split) t_own = min(t_own, m.run_start[k * m.numT + G.split - 1]);
+                }
             }
+            t0 = min(t_own, cb.trunk_ok[ch]);
+            const double* r = cb.trunk + (ch * (int64_t)m.numT + t0) * TRUNK_REC;
+            if (live) { x = r[lane]; w_pre = r[NS2 + lane]; w_post = r[2 * NS2 + lane]; }
+        }
+        for (int t = t0; t <= G.split && t < G.numT; ++t) {
+            if (t == m.sample_date) ancient_project(xbuf, lane, x);
             if (t == G.split) break;
-            double pu0, pu1, mu0, mu1;
-            mod.pulse(t, pu0, pu1);
-            mod.mig(t, mu0, mu1);
-            double pr = pu0 + pu1;
-            if (pr > 0) {
-                // PulseMigration (TwoPopulations.py:361-377)
-                int from = pu0 > 0 ? 0 : 1;
-                xbuf[lane] = x; lds_fence();
-                double pw_s[5], pw_m[5];
-                pw_s[0] = pw_m[0] = 1.0;
-                for (int i = 1; i < 5; ++i) { pw_s[i] = pw_s[i - 1] * (1.0 - pr); pw_m[i] = pw_m[i - 1] * pr; }
-                double nx = 0.0;
-                int n = live ? c_tab.pulse_n[from][lane] : 0;
-                for (int j = 0; j < n; ++j) {
-                    int ab = c_tab.pulse_ab[from][lane][j];
-                    int mul = ab >> 8, a = (ab >> 4) & 15, b = ab & 15;
-                    nx += xbuf[c_tab.pulse_src[from][lane][j]] * ((double)mul * pw_s[a] * pw_m[b]);
-                }
-                lds_fence();
-                x = nx;
-            }
-            double la0 = lcb[2 * t], la1 = lcb[2 * t + 1];
-            double T = G.T(t);
-            // largest total exit rate over the 44 states (4 lineages dominate)
-            double r40 = 6 * la0 + 4 * mu0, r04 = 6 * la1 + 4 * mu1;
-            double r31 = 3 * la0 + 3 * mu0 + mu1, r13 = 3 * la1 + 3 * mu1 + mu0;
-            double r22 = la0 + la1 + 2 * mu0 + 2 * mu1;
-            double q = T * fmax(fmax(r40, r04), fmax(fmax(r31, r13), r22));
-            if (!(q < 1e300)) { status = MISTI_NUMERIC; break; }
-            double rate[4] = {la0, la1, mu0, mu1};
-            double cf[MAXNZ];
-            for (int n = 0; n < MAXNZ; ++n) cf[n] = mlt[n] * rate[knd[n]] * T;
-            const double dT = (dc0 * la0 + dc1 * la1 + dc2 * mu0 + dc3 * mu1) * T;   // exit rate x T of this state
-            double wint = 0.0;
-            if (q <= Q_SWITCH) {
-                // uniformisation: M T = N - q I, p_{k+1} = N p_k/(k+1), i_{k+1} = (T p_k + q i_k)/(k+1)
-                const double dg = q - dT;
-                const double eq = exp(-q);
-                double p = eq * x, ii = 0.0;
-                double accp = p, acci = 0.0;
-                double b = eq, bprev = 1.0;
-                double inv_next = c_inv[1];
-                for (int k = 1; k < INV_TABLE - 1; ++k) {
-                    const double inv = inv_next;
-                    inv_next = c_inv[k + 1];
-                    xbuf[lane] = p;
-                    lds_fence();
-                    double r0 = xbuf[srcl[0]], r1 = xbuf[srcl[1]], r2 = xbuf[srcl[2]], r3 = xbuf[srcl[3]];
-                    lds_fence();
-                    double pn = (dg * p + ((cf[0] * r0 + cf[1] * r1) + (cf[2] * r2 + cf[3] * r3))) * inv;
-                    ii = (T * p + q * ii) * inv;
-                    p = pn;
-                    accp += p; acci += ii;
-                    bprev = b;
-                    b *= q * inv;
-                    if (bprev < 1e-19 && (double)k > q) break;
-                }
-                x = accp; wint = acci;
-            } else {
-                // Talbot contour, conjugate pairs folded: f = 2 Re sum_{k upper} (-c_k) (z_k - M T)^-1 x
-                double accp = 0.0, acci = 0.0;
-                bool stalled = false;
-                for (int nd = 0; nd < TALBOT_HALF; ++nd) {
-                    const double zr = c_tab.tal_zr[nd], zi = c_tab.tal_zi[nd], cr = c_tab.tal_cr[nd], ci = c_tab.tal_ci[nd];
-                    const double ar = zr + dT, ai = zi;
-                    const double den = 1.0 / (ar * ar + ai * ai);
-                    const double ir = ar * den, im = -ai * den;              // 1 / (z + D_i)
-                    double xr = x * ir, xi = x * im;
-                    int it = 0;
-                    for (; it < JACOBI_MAX; ++it) {
-                        xbuf[lane] = xr; xbuf[64 + lane] = xi;
-                        lds_fence();
-                        double sr = x + ((cf[0] * xbuf[srcl[0]] + cf[1] * xbuf[srcl[1]]) + (cf[2] * xbuf[srcl[2]] + cf[3] * xbuf[srcl[3]]));
-                        double si = (cf[0] * xbuf[64 + srcl[0]] + cf[1] * xbuf[64 + srcl[1]]) + (cf[2] * xbuf[64 + srcl[2]] + cf[3] * xbuf[64 + srcl[3]]);
-                        lds_fence();
-                        double nr = sr * ir - si * im, ni = sr * im + si * ir;
-                        bool moving = (fabs(nr - xr) + fabs(ni - xi)) > 4e-16 * (fabs(nr) + fabs(ni)) + 1e-300;
-                        xr = nr; xi = ni;
-                        if (!__any(moving)) break;
-                    }
-                    if (it >= JACOBI_MAX) stalled = true;
-                    const double wr = -(cr * xr - ci * xi), wi = -(cr * xi + ci * xr);
-                    const double zz = 1.0 / (zr * zr + zi * zi);
-                    const double gr = T * zr * zz, gi = -T * zi * zz;        // T / z
-                    accp += 2.0 * wr;
-                    acci += 2.0 * (wr * gr - wi * gi);
-                }
-                if (stalled) { status = MISTI_STIFF; break; }
-                x = accp; wint = acci;
-            }
-            if (t < m.sample_date) w_pre += wint; else w_post += wint;
+            const int st = twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post);
+            if (st != MISTI_OK) { status = st; break; }
         }
         if (status == MISTI_OK) {
             // two-population share of the spectrum: lanes 0..6 each sum one class
@@ -1620,9 +1719,20 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
     return hipGetLastError();
 }
 
+// chains the trunk buffer must hold for a batch of n_cand (the trunk runs only when
+// n_chains * TRUNK_MIN_SHARE <= n_cand); MISTI_NO_TRUNK=1 in the environment disables it
+int64_t trunk_capacity(int64_t n_cand) {
+    const char* e = getenv("MISTI_NO_TRUNK");              // read per call: tests toggle it
+    const bool off = e && e[0] && e[0] != '0';
+    return off ? 0 : n_cand / TRUNK_MIN_SHARE;
+}
+
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
+    if (cb.trunk_cap > 0)
+        hipLaunchKernelGGL(trunk_kernel, dim3((unsigned)cb.trunk_cap), dim3(64), (128 + 2 * (size_t)(m.numT + 1)) * sizeof(double), stream,
+                           m, n_cand, params, cb);
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (m.flags & MISTI_CPFIT)
         hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,

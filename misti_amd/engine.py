@@ -171,6 +171,12 @@ class Engine:
         ``torch.cuda.current_stream().cuda_stream``; ``None`` restores the own stream."""
         _lib.check(self._lib.misti_set_stream(self._ctx, C.c_void_p(stream_handle) if stream_handle else None))
 
+    def stream_handle(self):
+        """The hipStream_t (int) this engine issues on - its own non-blocking stream unless replaced."""
+        h = C.c_void_p()
+        _lib.check(self._lib.misti_get_stream(self._ctx, C.byref(h)))
+        return h.value or 0
+
     def evaluate_dev(self, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0):
         """``misti_eval_batch_dev``: raw device addresses (ints); asynchronous."""
         v = lambda p: C.c_void_p(int(p)) if p else None

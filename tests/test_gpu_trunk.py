@@ -1,0 +1,108 @@
+"""The trunk (shared 44-state propagation of the candidates of one chain) must
+not change a single bit: same inputs, same arithmetic, only fewer repetitions.  Every case is
+evaluated twice through the C ABI - MISTI_NO_TRUNK=1 (every candidate walks all its intervals) and
+the default - and every output compared exactly.  Also checks against the oracle that the trunk
+path is the one that meets parity (not merely self-consistent)."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from parity import llk_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def both_ways(make_engine, split, params, rows):
+    out = {}
+    for off in ("1", "0"):
+        os.environ["MISTI_NO_TRUNK"] = off
+        try:
+            with make_engine() as e:
+                out[off] = e.evaluate(split, params, rows, want_lc=True, want_pr=True)
+        finally:
+            os.environ.pop("MISTI_NO_TRUNK", None)
+    return out["1"], out["0"]
+
+
+def assert_identical(a, b):
+    assert np.array_equal(a.status, b.status)
+    for name in ("llk", "jafs", "lc", "runaway"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert np.array_equal(x, y, equal_nan=True), name
+    assert np.array_equal(a.pr[:, :-1], b.pr[:, :-1], equal_nan=True)      # last row: work counters of the correction
+
+
+def small_grid(self_consistent=False, sample_date=0):
+    """numT = 32 grid; with self_consistent the PSMC-like rates are derived from a true model by the
+    forward map, so that the lambda-correction succeeds around the truth in every fitting mode."""
+    from misti_amd import synth, io as mio
+    inp = mio.merge_psmc(mio.read_psmc_file(io.StringIO(synth.psmc_text(16, 1, synth.THETA_1))),
+                         mio.read_psmc_file(io.StringIO(synth.psmc_text(17, 2, synth.THETA_2))))
+    if self_consistent:
+        s0 = max(2, sample_date)
+        _, lh, _ = synth.self_consistent(inp, 20, [[1, s0, 20, 0.2, 0], [2, max(1, sample_date), 9, 0.15, 0]], [[2, 6, 0.1, 0]])
+        inp.lambdas = lh
+    return inp
+
+
+@pytest.mark.parametrize("flags", [dict(cpfit=True, smooth=True), dict(cpfit=False, smooth=True), dict(cpfit=True, smooth=False),
+                                   dict(cpfit=True, smooth=True, unfolded=True, sample_date=3), dict(true_eps=True, smooth=True)],
+                         ids=["cpfit", "default-fit", "nosmooth", "ancient-unfolded", "trueEPS"])
+def test_trunk_is_bit_identical_small(flags):
+    """numT = 32: 28 split values (a third fractional) x 4 parameter vectors, one band following the split,
+    one fixed band, one optimised pulse."""
+    from misti_amd.engine import Engine
+    sd = flags.get("sample_date", 0)
+    inp = small_grid(True, sd)
+    numT = len(inp.lambdas)
+    bands = [(0, max(2, sd), -1, 0.0, 0), (1, max(1, sd), 9, 0.15, -1)]
+    pulses = [(1, 6, 0.0, 1)]
+    rng = np.random.default_rng(11)
+    splits = np.arange(10, numT - 4, dtype=float)
+    splits[::3] += rng.uniform(0.1, 0.9, len(splits[::3]))
+    par = np.array([[0.02, 0.0], [0.2, 0.1], [0.6, 0.3], [3.0, 0.05]])        # the last one runs into the runaway regime
+    split = np.repeat(splits, len(par))
+    params = np.tile(par, (len(splits), 1))
+    rows = [[3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]]
+    a, b = both_ways(lambda: Engine(inp.times, inp.lambdas, bands, pulses, n_param=2, **flags), split, params, rows)
+    assert len(split) >= 8 * len(par)                                        # the trunk is active for this batch
+    assert_identical(a, b)
+    assert (b.status == 0).mean() > 0.5
+
+
+def test_trunk_is_bit_identical_on_the_headline_grid():
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a))
+    a, b = both_ways(lambda: Engine(w.times, w.lh, **w.engine_kwargs()), w.split_time, w.params, w.jsfs)
+    assert_identical(a, b)
+
+
+def test_trunk_path_meets_parity_with_the_oracle():
+    """A chain-sharing batch small enough for the oracle: every candidate against the oracle."""
+    from misti_amd.engine import Engine
+    from oracle.misti_oracle import OracleModel
+    inp = small_grid(True)
+    splits = np.arange(12, 28, dtype=float)
+    splits[1::4] += 0.37
+    rates = np.array([0.05, 0.3])
+    split = np.repeat(splits, 2)
+    params = np.tile(rates, len(splits)).reshape(-1, 1)
+    row = [3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]
+    with Engine(inp.times, inp.lambdas, [(0, 2, -1, 0.0, 0), (1, 1, 9, 0.15, -1)], [(1, 6, 0.1, -1)], n_param=1, cpfit=True, smooth=True) as e:
+        res = e.evaluate(split, params, [row])
+    assert (res.status == 0).all()
+    checked = 0
+    for c in range(len(split)):
+        end = int(np.ceil(split[c]))
+        m = OracleModel(list(inp.times), [list(x) for x in inp.lambdas], row, float(split[c]), [[1, 2, end, float(params[c, 0]), 1], [2, 1, 9, 0.15, 0]], [[2, 6, 0.1, 0]],
+                        cpfit=True, smooth=True)
+        want = m.jafs_likelihood([float(params[c, 0])])
+        if res.runaway[c] >= 5.0:            # reference-indeterminate: only loosely comparable
+            assert abs(res.llk[c, 0] - want) <= 1e-3 * abs(want)
+            continue
+        checked += 1
+        assert abs(res.llk[c, 0] - want) <= llk_tol(want, row, m.JAFS, False), (c, split[c], params[c])
+    assert checked >= 16
