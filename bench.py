@@ -186,6 +186,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_issue = [0.0]
+
     def timed(lanes, timing):
         """W warmup + K timed steps issued round-robin on `lanes`; returns seconds (max over ranks)."""
         for i in range(a.warmup):
@@ -197,6 +199,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(a.steps):
             lanes[i % len(lanes)].step()
+        host_issue[0] = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
@@ -208,6 +211,7 @@ def main():
     n_streams = max(1, a.streams)
     main_lanes = [Lane() for i in range(n_streams)]
     dt = timed(main_lanes, timing=False)
+    issue_main = host_issue[0]
     # strictly serial pass on one stream: per-kernel durations (HIP events on the launch stream) and the serial rate
     serial = main_lanes[0]
     eng = serial.eng
@@ -259,6 +263,7 @@ def main():
         out["status_fraction"] = {"ok": float(ok.mean()), "correction_failed": float((status == 2).mean()),
                                   "stiff": float((status == 6).mean()), "numeric": float((status == 5).mean())}
         out["spectrum_evals_per_s"] = world * n * a.steps / dt
+        out["host_issue_ms_per_step"] = 1e3 * issue_main / a.steps
         out["serial"] = {"streams": 1, "value": world * n * R * k_serial / dt_serial, "ms_per_step": 1e3 * dt_serial / k_serial, "steps": k_serial,
                          "note": "the same step issued strictly one after another on one stream: bounded by the longest "
                                  "lambda-correction chain of the batch (up to ~830 dependent residual evaluations in the runaway "

@@ -72,7 +72,7 @@ struct misti_ctx {
     DevBuf ws_diag;                     // per candidate: largest corrected rate x interval length of the last batch
     int64_t diag_n = 0;
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
-    DevBuf ws_chain_f64, ws_chain_i32, ws_scratch, ws_temp;   // chain buffers (kernel 1 -> kernel 2), discovery scratch
+    DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -171,19 +171,16 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (!d_status) { HIP_TRY(c->ws_status.reserve((size_t)n_cand * sizeof(int32_t))); d_status = c->ws_status.as<int32_t>(); }
     if (n_cand > INT32_MAX / 8) return fail(MISTI_E_LIMIT, "n_cand too large for one call");
     const size_t nc = (size_t)n_cand, numT = (size_t)c->dm.numT;
-    // chain machinery: one allocation, carved below
-    size_t temp_bytes = 0;
-    HIP_TRY(misti::chain_temp_bytes(n_cand, &temp_bytes));
-    const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
+    // chain machinery: one allocation per type, carved below
+    const size_t tsize = misti::chain_table_size(n_cand);
     const size_t ntr = (size_t)misti::trunk_capacity(n_cand);
-    const size_t i32_n = 1 + 6 * nc + 1 + ntr;                   // n_chains, rep, len, of, fail_t, fail_status, tail_status, trunk_ok
-    const size_t scratch_bytes = nc * 2 * sizeof(uint64_t) + nc * 4 * sizeof(int32_t);
+    const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
+    const size_t i32_n = 2 + 3 * tsize + 6 * nc + ntr;      // n_chains | table, slot_chain, slot_len | slot_of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
     HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
-    HIP_TRY(c->ws_scratch.reserve(scratch_bytes));
-    HIP_TRY(c->ws_temp.reserve(temp_bytes + 16));
     HIP_TRY(c->ws_order.reserve(nc * sizeof(int32_t)));
     if (ntr) HIP_TRY(c->ws_trunk.reserve(ntr * numT * misti::TRUNK_REC * sizeof(double)));
+    if (n_rep > 0) HIP_TRY(c->consts.reserve((size_t)n_rep * sizeof(double)));
     misti::ChainBufs cb;
     {
         double* d = c->ws_chain_f64.as<double>();
@@ -194,31 +191,36 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.tail_state = d;
         int32_t* q = c->ws_chain_i32.as<int32_t>();
         cb.n_chains = q; q += 2;
-        cb.rep = q; q += nc; cb.len = q; q += nc; cb.of = q; q += nc;
+        cb.table = q; q += tsize; cb.slot_chain = q; q += tsize; cb.slot_len = q; q += tsize;
+        cb.slot_of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
         cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc;
         cb.trunk_ok = q;
+        cb.tmask = (uint32_t)(tsize - 1);
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
         cb.trunk_cap = (int64_t)ntr;
     }
+    // a batch is five launches (six with more than LLK_INLINE_MAX replicates): prepare | discover | chains |
+    // trunks + tails | candidates (+ replicate epilogue).  Few launches matter when many batches are in flight.
     int32_t* d_order = c->ws_order.as<int32_t>();
+    double* d_consts = n_rep > 0 ? c->consts.as<double>() : nullptr;
+    const bool llk_inline = n_rep > 0 && n_rep <= misti::LLK_INLINE_MAX;
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY(misti::launch_order(n_cand, d_split, c->dm.numT, d_order, c->stream));
-    HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->ws_scratch.p, c->ws_temp.p, temp_bytes, c->stream));
+    HIP_TRY(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream));
+    HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->stream));
     HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, c->stream));
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
-    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(), c->stream));
+    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
+                                   n_rep, d_jsfs, d_consts, d_llk, c->stream));
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
-    if (n_rep > 0) {
-        HIP_TRY(c->consts.reserve((size_t)n_rep * sizeof(double)));
-        HIP_TRY(misti::launch_llh_const(n_rep, d_jsfs, c->consts.as<double>(), c->unfolded, c->stream));
+    if (n_rep > 0 && !llk_inline) {
         if (int r = record_begin(c, 2, &a, &b)) return r;
-        HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, c->consts.as<double>(), d_llk, c->unfolded, c->stream));
+        HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, d_consts, d_llk, c->unfolded, c->stream));
         if (int r = record_end(c, 2, a, b)) return r;
         if (c->timing) c->launches[2] += 1;
     }
@@ -347,7 +349,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_scratch, &c->ws_temp, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->st_split, &c->st_params, &c->st_jsfs,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->st_split, &c->st_params, &c->st_jsfs,
                     &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     for (int w = 0; w < 3; ++w)

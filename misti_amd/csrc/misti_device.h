@@ -41,12 +41,18 @@ struct DevModel {
     misti_pulse_t pulses[MISTI_MAX_PULSES];
 };
 
-// Device buffers of the chain machinery (see correct_kernel).
+// Device buffers of the chain machinery (see correct_kernel).  Candidates with bitwise identical
+// parameter vectors share a chain; chains are found by inserting every candidate into an open-addressing
+// table keyed by its parameters (discover_kernel): the first one in a slot owns the chain.
 struct ChainBufs {
     int32_t* n_chains;      // [1]
+    int32_t* table;         // [tsize] slot -> owner candidate + 1, 0 = empty
+    int32_t* slot_chain;    // [tsize] slot -> chain
+    int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
+    int32_t* slot_of;       // [n] candidate -> slot
+    int32_t* chain_slot;    // [n] chain -> slot
     int32_t* rep;           // [n] chain -> a member candidate (its parameters)
-    int32_t* len;           // [n] chain -> number of full intervals needed (max over members)
-    int32_t* of;            // [n] candidate -> chain
+    uint32_t tmask;         // tsize - 1 (tsize a power of two >= 2 n)
     double* lc;             // [n][numT][2]     per chain: corrected rates, unsmoothed
     double* trace;          // [n][numT+1][6]   per chain: pair state before interval t (.Pr layout)
     int32_t* fail_t;        // [n] per chain: first failing interval, INT_MAX if none
@@ -60,16 +66,23 @@ struct ChainBufs {
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
 };
 
+__device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.slot_chain[cb.slot_of[cand]]; }
+__device__ __forceinline__ int chain_len(const ChainBufs& cb, int64_t ch) { return cb.slot_len[cb.chain_slot[ch]]; }
+
+// Replicate epilogue fused into the spectrum kernel up to this many replicates (one launch less per batch).
+constexpr int LLK_INLINE_MAX = 8;
+
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
 int64_t trunk_capacity(int64_t n_cand);
-hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream);
-hipError_t chain_temp_bytes(int64_t n, size_t* bytes);
-hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, ChainBufs cb,
-                                  void* scratch, void* temp, size_t temp_bytes, hipStream_t stream);
+uint32_t chain_table_size(int64_t n_cand);
+hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
+                          int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
+hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag, hipStream_t stream);
+                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);

@@ -28,7 +28,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
 
 #include "misti_device.h"
 
@@ -845,21 +844,30 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 // trf_no_bounds (trf.py:401-560), so the items of a wavefront never wait for each other
 // interval by interval.
 template <bool CPFIT, int GROUP, bool TAIL>
-__global__ __launch_bounds__(64)
-void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+__device__ __forceinline__
+void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
+                  int64_t block, double* lds) {
     const int lane = lane_id();
     const int sub = lane & (GROUP - 1);
-    const int64_t slot = ((int64_t)blockIdx.x * (64 / GROUP)) + (lane / GROUP);
+    const int64_t slot = (block * (64 / GROUP)) + (lane / GROUP);
+    const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
+    if (TAIL) {
+        // a wave none of whose items has a fractional split has nothing to do: leave before staging
+        bool mine = false;
+        if (slot < n_live) { const double st = split_time[slot]; mine = st != floor(st); }
+        if (!__any(mine)) {
+            if (slot < n_live && sub == 0) cb.tail_status[slot] = MISTI_OK;
+            return;
+        }
+    } else if (block * (64 / GROUP) >= n_live) return;
     // the shared grid (interval lengths, PSMC rates) staged in LDS: every pass of the state
     // machine of some item reads it, and an L2 round trip per read dominated the kernel
-    extern __shared__ double lds[];
     {
         const int nt = m.numT - 1, nl = 2 * m.numT;
         for (int i = lane; i < nt; i += 64) lds[i] = m.times[i];
         for (int i = lane; i < nl; i += 64) lds[nt + i] = m.lh[i];
     }
     __syncthreads();
-    const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
     if (slot >= n_live) return;
     const int64_t cand = TAIL ? slot : (int64_t)cb.rep[slot];      // whose parameters
     const double* par = params ? params + cand * m.n_param : nullptr;
@@ -872,7 +880,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
     if (!TAIL) {
         status = MISTI_OK;
         for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
-        G.numT0 = m.numT; G.numT = m.numT; G.split = cb.len[slot]; G.ins = -1; G.frac = 0.0;
+        G.numT0 = m.numT; G.numT = m.numT; G.split = chain_len(cb, slot); G.ins = -1; G.frac = 0.0;
         lc_w = cb.lc + slot * (int64_t)m.numT * 2;
         tr_w = cb.trace + slot * (int64_t)(m.numT + 1) * 6;
         ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
@@ -882,7 +890,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
         status = setup_candidate(m, split_time[cand], par, G);
         if (sub == 0) cb.tail_status[cand] = MISTI_OK;
         if (status != MISTI_OK || G.ins < 0) return;               // nothing to do: no fractional split
-        const int64_t ch = cb.of[cand];
+        const int64_t ch = chain_of(cb, cand);
         if (cb.fail_t[ch] < G.ins) return;                         // the chain failed before this candidate's tail
         t = G.ins;
         const double* r = cb.trace + (ch * (int64_t)(m.numT + 1) + t) * 6;
@@ -1083,6 +1091,50 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
     }
 }
 
+template <bool CPFIT, int GROUP>
+__global__ __launch_bounds__(64)
+void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+    extern __shared__ double lds[];
+    correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds);
+}
+
+// ---- replicate epilogue pieces ----
+// llh_const of SetJAFS (MigrationInference.py:217-227) for one replicate
+__device__ __forceinline__ double llh_const_of(const double* __restrict__ row, int unfolded) {
+    const double* d = row + 1;
+    double snps = 0.0;
+    for (int i = 0; i < 7; ++i) snps += d[i];
+    double c = lgamma(snps + 1.0);
+    if (unfolded) { for (int i = 0; i < 7; ++i) c -= lgamma(d[i] + 1.0); }
+    else {
+        c -= lgamma(d[0] + d[6] + 1.0);
+        c -= lgamma(d[1] + d[5] + 1.0);
+        c -= lgamma(d[2] + d[4] + 1.0);
+        c -= lgamma(d[3] + 1.0);
+    }
+    return c;
+}
+
+// Multinomial log-likelihood of one replicate (MigrationInference.py:600-609) from the logs of the
+// spectrum classes (folded: classes 0+6, 1+5, 2+4, 3).  Shared by llk_kernel and the epilogue of
+// the spectrum kernel so that both give the same bits.
+__device__ __forceinline__ double log_class(const double* J, int i, int unfolded) {
+    if (unfolded) return log(J[i]);
+    return (i < 3) ? log(J[i] + J[6 - i]) : (i == 3 ? log(J[3]) : 0.0);
+}
+__device__ __forceinline__ double llk_of(const double* __restrict__ row, double cst, const double* lj, int unfolded) {
+    const double* d = row + 1;
+    double a = cst;
+    if (unfolded) { for (int i = 0; i < 7; ++i) a = fma(d[i], lj[i], a); }
+    else {
+        a = fma(d[0] + d[6], lj[0], a);
+        a = fma(d[1] + d[5], lj[1], a);
+        a = fma(d[2] + d[4], lj[2], a);
+        a = fma(d[3], lj[3], a);
+    }
+    return a;
+}
+
 // ---- two-population propagation shared by the trunk and the candidate kernel ----
 // Row view of the 44-state generator for state `lane`, kept in registers.
 struct TwoPopRow {
@@ -1243,7 +1295,7 @@ __device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, d
 // run its split cuts (t_own in spectrum_kernel) and adds only its own 0-5 intervals - on a
 // split x rate grid ~14x less propagation work.  The arithmetic per interval is the same code
 // (twopop_interval) on the same inputs, so a candidate's result is bit-identical with or without
-// the trunk (tests/test_gpu_grid.py::test_trunk_is_bit_identical).
+// the trunk (tests/test_gpu_trunk.py).
 // Active only when sharing pays: n_chains * TRUNK_MIN_SHARE <= n_cand (decided on the device, the
 // chain count never visits the host).
 __device__ __forceinline__ bool trunk_active(const ChainBufs& cb, int64_t n_cand) {
@@ -1251,16 +1303,14 @@ __device__ __forceinline__ bool trunk_active(const ChainBufs& cb, int64_t n_cand
     return cb.trunk_cap > 0 && nch <= cb.trunk_cap && nch * TRUNK_MIN_SHARE <= n_cand;
 }
 
-__global__ __launch_bounds__(64)
-void trunk_kernel(DevModel m, int64_t n_cand, const double* __restrict__ params, ChainBufs cb) {
-    extern __shared__ double lds[];
+__device__ __forceinline__
+void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ params, const ChainBufs& cb, int64_t ch, double* lds) {
     const int lane = lane_id();
-    const int64_t ch = blockIdx.x;
     if (!trunk_active(cb, n_cand) || ch >= cb.n_chains[0]) return;
     double* xbuf = lds;
     double* lcb = lds + 128;
     const int ft = cb.fail_t[ch];
-    int Lt = cb.len[ch];
+    int Lt = chain_len(cb, ch);
     if (ft < Lt) Lt = ft;                                   // members beyond the failing interval have no value anyway
     const double* par = params ? params + (int64_t)cb.rep[ch] * m.n_param : nullptr;
     Grid G;
@@ -1287,6 +1337,18 @@ void trunk_kernel(DevModel m, int64_t n_cand, const double* __restrict__ params,
     if (lane == 0) cb.trunk_ok[ch] = ok;
 }
 
+// Everything that waits for the chains and that the candidate kernel waits for, in ONE launch: the
+// trunks (blocks below trunk_cap, dispatched first: they are the long ones) and the tails of the
+// lambda-correction (the shortened last interval of candidates with a fractional split).  A launch
+// costs a queue round trip, which is what limits the rate when many batches are in flight.
+template <bool CPFIT, int GROUP>
+__global__ __launch_bounds__(64)
+void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+    extern __shared__ double lds[];
+    if ((int64_t)blockIdx.x < cb.trunk_cap) trunk_body(m, n_cand, params, cb, (int64_t)blockIdx.x, lds);
+    else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - cb.trunk_cap, lds);
+}
+
 // Kernel 2: post-split rates (:355-376), Smooth (:380-405) and the expected joint spectrum
 // (JAFSpectrum, :467-540).  One wavefront per candidate; lane = interval in the prologue,
 // lane = state of the 44-state chain afterwards.
@@ -1295,7 +1357,8 @@ template <bool CPFIT>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
-                     double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out) {
+                     double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out,
+                     int n_inline, const double* __restrict__ jsfs, const double* __restrict__ consts, double* __restrict__ llk_out) {
     extern __shared__ double lds[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -1311,7 +1374,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
     mod.cache();
     // ---- this candidate's share of its chain (+ its own tail interval after a fractional split)
-    const int64_t ch = cb.of[cand];
+    const int64_t ch = chain_of(cb, cand);
     const int nfull = (G.ins >= 0) ? G.ins : G.split;          // intervals taken from the chain
     const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
     const double* tr_ch = cb.trace + ch * (int64_t)(m.numT + 1) * 6;
@@ -1340,6 +1403,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     if (status != MISTI_OK) {
         if (lane == 0) { status_out[cand] = status; if (diag_out) diag_out[cand] = NAN; }
         if (lane < 7) jafs_out[cand * 7 + lane] = NAN;
+        if (lane < n_inline) llk_out[cand * n_inline + lane] = -INFINITY;
         if (lc_o)                            // partial rates (up to the failing interval) for diagnostics
             for (int i = lane; i < 2 * lc_rows; i += 64) {
                 const int t = i >> 1;
@@ -1508,6 +1572,17 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         for (int c = 0; c < 7; ++c) if (lane == c) v = jafs[c];
         jafs_out[cand * 7 + lane] = (status == MISTI_OK) ? v : NAN;
     }
+    // ---- replicate epilogue for small replicate counts (:600-609): lane r = replicate r ----
+    if (lane < n_inline) {
+        double out = -INFINITY;
+        if (status == MISTI_OK) {
+            const int unfolded = (m.flags & MISTI_UNFOLDED) ? 1 : 0;
+            double lj[7];
+            for (int i = 0; i < 7; ++i) lj[i] = log_class(jafs, i, unfolded);
+            out = llk_of(jsfs + (int64_t)lane * 8, consts[lane], lj, unfolded);
+        }
+        llk_out[cand * n_inline + lane] = out;
+    }
 }
 
 // ---- chain discovery: candidates with bitwise identical parameter vectors share a chain ----
@@ -1517,117 +1592,98 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
     return z ^ (z >> 31);
 }
-__global__ void chain_key_kernel(int64_t n, int P, const double* __restrict__ params, uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+
+// Every candidate is inserted into an open-addressing table keyed by the bits of its parameter
+// vector (linear probing; the table was zeroed by prepare_kernel).  The first candidate in a slot
+// owns the chain and draws the chain id; equal hashes are verified against the owner's parameters
+// (read-only input), so a collision costs a probe, never correctness.  Chain ids depend on the
+// order of arrival - they only name buffers; no result depends on them.
+__global__ __launch_bounds__(256)
+void discover_kernel(int64_t n, int P, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t h = 0x243f6a8885a308d3ull;
-    for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(params[i * P + k]));
-    keys[i] = h;
-    vals[i] = (int32_t)i;
-}
-// head[i] = 1 where the i-th sorted candidate starts a run of identical parameter vectors
-// (equal hashes are verified, so a hash collision only costs sharing, never correctness)
-__global__ void chain_head_kernel(int64_t n, int P, const double* __restrict__ params, const uint64_t* __restrict__ keys,
-                                  const int32_t* __restrict__ idx, int32_t* __restrict__ head) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int h = 1;
-    if (i > 0 && keys[i] == keys[i - 1]) {
-        h = 0;
-        const double* a = params + (int64_t)idx[i] * P;
-        const double* b = params + (int64_t)idx[i - 1] * P;
-        for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) h = 1;
+    const double* a = params + i * P;
+    for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
+    uint32_t s = (uint32_t)(h >> 20) & cb.tmask;
+    for (;;) {
+        const int prev = atomicCAS(&cb.table[s], 0, (int)i + 1);
+        if (prev == 0) {
+            const int ch = atomicAdd(cb.n_chains, 1);
+            cb.chain_slot[ch] = (int32_t)s;
+            cb.rep[ch] = (int32_t)i;
+            cb.slot_chain[s] = ch;
+            break;
+        }
+        const double* b = params + (int64_t)(prev - 1) * P;
+        bool same = true;
+        for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) same = false;
+        if (same) break;
+        s = (s + 1) & cb.tmask;
     }
-    head[i] = h;
-}
-__global__ void chain_assign_kernel(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ head, const int32_t* __restrict__ scan,
-                                    const double* __restrict__ split_time, int numT, ChainBufs cb) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int ch = scan[i] - 1;
-    const int c = idx[i];
-    cb.of[c] = ch;
-    if (head[i]) cb.rep[ch] = c;
-    const double st = split_time[c];
+    cb.slot_of[i] = (int32_t)s;
+    const double st = split_time[i];
     int need = 0;
     if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
-    atomicMax(&cb.len[ch], need);
-    if (i == n - 1) cb.n_chains[0] = scan[i];
+    atomicMax(&cb.slot_len[s], need);
 }
 
-hipError_t chain_temp_bytes(int64_t n, size_t* bytes) {
-    size_t a = 0, b = 0;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, a, (uint64_t*)nullptr, (uint64_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
-    if (e != hipSuccess) return e;
-    e = hipcub::DeviceScan::InclusiveSum(nullptr, b, (int32_t*)nullptr, (int32_t*)nullptr, (int)n);
-    *bytes = a > b ? a : b;
-    return e;
+uint32_t chain_table_size(int64_t n_cand) {
+    uint32_t t = 64;
+    while ((int64_t)t < 2 * n_cand) t <<= 1;
+    return t;
 }
 
-// scratch: keys[2n] u64 | vals[2n] i32 | head[n] i32 | scan[n] i32 ; temp: hipcub storage
-hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, ChainBufs cb,
-                                  void* scratch, void* temp, size_t temp_bytes, hipStream_t stream) {
+hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    uint64_t* keys = (uint64_t*)scratch;
-    uint64_t* keys2 = keys + n;
-    int32_t* vals = (int32_t*)(keys2 + n);
-    int32_t* vals2 = vals + n;
-    int32_t* head = vals2 + n;
-    int32_t* scan = head + n;
-    const unsigned nb = (unsigned)((n + 255) / 256);
-    hipError_t e = hipMemsetAsync(cb.len, 0, n * sizeof(int32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain_key_kernel, dim3(nb), dim3(256), 0, stream, n, P, params, keys, vals);
-    e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)n, 0, 64, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain_head_kernel, dim3(nb), dim3(256), 0, stream, n, P, params, keys2, vals2, head);
-    e = hipcub::DeviceScan::InclusiveSum(temp, temp_bytes, head, scan, (int)n, stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(chain_assign_kernel, dim3(nb), dim3(256), 0, stream, n, vals2, head, scan, split, numT, cb);
+    hipLaunchKernelGGL(discover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, P, params, split, numT, cb);
     return hipGetLastError();
 }
 
-// Dispatch order: candidates sorted by descending split index (counting sort, one workgroup).
-// Work per candidate grows with the number of two-population intervals, and the workgroup
-// dispatcher hands blocks out in index order, so the longest chains start first and the
-// short ones fill in behind them.  The order never affects a candidate's result.
+// First launch of a batch, everything that depends on the inputs alone:
+//  * block 0: dispatch order - candidates sorted by descending split index (counting sort).  Work
+//    per candidate grows with the number of two-population intervals and the dispatcher hands
+//    blocks out in index order, so the longest start first.  The order never affects a result;
+//  * the other blocks: zero the chain table, llh_const of every replicate.
 __global__ __launch_bounds__(256)
-void order_kernel(int64_t n_cand, const double* __restrict__ split_time, int numT, int32_t* __restrict__ order) {
-    __shared__ int hist[MISTI_MAX_NUMT + 4];
-    const int nb = numT + 3;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
-    for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
-    __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
+void prepare_kernel(int64_t n_cand, const double* __restrict__ split_time, int numT, int32_t* __restrict__ order, ChainBufs cb,
+                    int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
+    if (blockIdx.x == 0) {
+        __shared__ int hist[MISTI_MAX_NUMT + 4];
+        const int nb = numT + 3;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
+        for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
+        __syncthreads();
+        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } cb.n_chains[0] = 0; }
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
+        if (gridDim.x > 1) return;
+    }
+    const int64_t nthr = (int64_t)(gridDim.x > 1 ? gridDim.x - 1 : 1) * blockDim.x;
+    const int64_t tid = (int64_t)(gridDim.x > 1 ? blockIdx.x - 1 : 0) * blockDim.x + threadIdx.x;
+    const int64_t tsize = (int64_t)cb.tmask + 1;
+    for (int64_t i = tid; i < tsize; i += nthr) { cb.table[i] = 0; cb.slot_len[i] = 0; }
+    for (int64_t r = tid; r < n_rep; r += nthr) consts[r] = llh_const_of(jsfs + r * 8, unfolded);
 }
 
-hipError_t launch_order(int64_t n_cand, const double* split, int numT, int32_t* order, hipStream_t stream) {
+hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
+                          int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
-    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, stream, n_cand, split, numT, order);
+    const int64_t items = ((int64_t)cb.tmask + 1 > n_rep ? (int64_t)cb.tmask + 1 : n_rep);
+    int64_t nb = 1 + (items + 256 * 8 - 1) / (256 * 8);
+    if (nb > 257) nb = 257;
+    hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)nb), dim3(256), 0, stream, n_cand, split, numT, order, cb, n_rep, jsfs, consts, unfolded);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------- replicate epilogue --
-// llh_const of SetJAFS (MigrationInference.py:217-227): one thread per replicate.
+// llh_const of SetJAFS (MigrationInference.py:217-227): one thread per replicate (misti_llk_dev).
 __global__ void llh_const_kernel(int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rep) return;
-    const double* d = jsfs + r * 8 + 1;
-    double snps = 0.0;
-    for (int i = 0; i < 7; ++i) snps += d[i];
-    double c = lgamma(snps + 1.0);
-    if (unfolded) { for (int i = 0; i < 7; ++i) c -= lgamma(d[i] + 1.0); }
-    else {
-        c -= lgamma(d[0] + d[6] + 1.0);
-        c -= lgamma(d[1] + d[5] + 1.0);
-        c -= lgamma(d[2] + d[4] + 1.0);
-        c -= lgamma(d[3] + 1.0);
-    }
-    consts[r] = c;
+    consts[r] = llh_const_of(jsfs + r * 8, unfolded);
 }
 
 // llk[c][r] = const[r] + sum_i data[r][i] log JAFS[c][i]  (folded: pairs 0+6, 1+5, 2+4, 3)
@@ -1640,32 +1696,10 @@ void llk_kernel(int64_t n_cand, const double* __restrict__ jafs, const int32_t* 
     __shared__ double lj[7];
     const int64_t c = blockIdx.y;
     const int st = status ? status[c] : MISTI_OK;
-    if (threadIdx.x < 7) {
-        const double* J = jafs + c * 7;
-        double v;
-        if (unfolded) v = log(J[threadIdx.x]);
-        else {
-            int i = threadIdx.x;
-            v = (i < 3) ? log(J[i] + J[6 - i]) : (i == 3 ? log(J[3]) : 0.0);
-        }
-        lj[threadIdx.x] = v;
-    }
+    if (threadIdx.x < 7) lj[threadIdx.x] = log_class(jafs + c * 7, threadIdx.x, unfolded);
     __syncthreads();
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (int64_t)gridDim.x * blockDim.x) {
-        double out;
-        if (st != MISTI_OK) out = -INFINITY;
-        else {
-            const double* d = jsfs + r * 8 + 1;
-            double a = consts[r];
-            if (unfolded) { for (int i = 0; i < 7; ++i) a += d[i] * lj[i]; }
-            else {
-                a += (d[0] + d[6]) * lj[0];
-                a += (d[1] + d[5]) * lj[1];
-                a += (d[2] + d[4]) * lj[2];
-                a += d[3] * lj[3];
-            }
-            out = a;
-        }
+        const double out = (st != MISTI_OK) ? -INFINITY : llk_of(jsfs + r * 8, consts[r], lj, unfolded);
         llk[c * n_rep + r] = out;
     }
 }
@@ -1682,14 +1716,6 @@ hipError_t upload_tables(const DevTables& t) {
 
 size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
 
-template <bool CPFIT, int GROUP, bool TAIL>
-static void launch_correct_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
-    const int per_wave = 64 / GROUP;
-    dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
-    const size_t lds = (size_t)(3 * m.numT - 1) * sizeof(double);
-    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP, TAIL>), grid, dim3(64), lds, stream, m, n_items, cb, split, params);
-}
-
 // Work items per wavefront: 8 when the batch fills the chip several times over, fewer for small
 // batches (less divergence between the items of a wave, more wavefronts to overlap latency).
 int correct_cands_per_wave(int64_t n_cand) {
@@ -1700,22 +1726,38 @@ int correct_cands_per_wave(int64_t n_cand) {
     return cpw;
 }
 
-template <bool TAIL>
-static void launch_correct_mode(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
-    const bool cp = m.flags & MISTI_CPFIT;
-    switch (correct_cands_per_wave(n_items)) {
-        case 8: cp ? launch_correct_t<true, 8, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 8, TAIL>(m, n_items, cb, split, params, stream); break;
-        case 4: cp ? launch_correct_t<true, 16, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 16, TAIL>(m, n_items, cb, split, params, stream); break;
-        case 2: cp ? launch_correct_t<true, 32, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 32, TAIL>(m, n_items, cb, split, params, stream); break;
-        default: cp ? launch_correct_t<true, 64, TAIL>(m, n_items, cb, split, params, stream) : launch_correct_t<false, 64, TAIL>(m, n_items, cb, split, params, stream); break;
-    }
+static size_t correct_lds_bytes(int numT) { return (size_t)(3 * numT - 1) * sizeof(double); }
+static size_t trunk_lds_bytes(int numT) { return (128 + 2 * (size_t)(numT + 1)) * sizeof(double); }
+
+template <bool CPFIT, int GROUP>
+static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+    const int per_wave = 64 / GROUP;
+    dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
+    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params);
 }
 
-// chains (the number of live chains is read on the device: slots beyond it exit at once), then tails
+template <bool CPFIT, int GROUP>
+static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+    const int per_wave = 64 / GROUP;
+    dim3 grid((unsigned)(cb.trunk_cap + (n_cand + per_wave - 1) / per_wave));
+    size_t lds = correct_lds_bytes(m.numT);
+    if (trunk_lds_bytes(m.numT) > lds) lds = trunk_lds_bytes(m.numT);
+    hipLaunchKernelGGL((post_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, cb, split, params);
+}
+
+#define MISTI_DISPATCH_GROUP(FN, ...)                                                                   \
+    switch (correct_cands_per_wave(n_cand)) {                                                            \
+        case 8: cp ? FN<true, 8>(__VA_ARGS__) : FN<false, 8>(__VA_ARGS__); break;                        \
+        case 4: cp ? FN<true, 16>(__VA_ARGS__) : FN<false, 16>(__VA_ARGS__); break;                      \
+        case 2: cp ? FN<true, 32>(__VA_ARGS__) : FN<false, 32>(__VA_ARGS__); break;                      \
+        default: cp ? FN<true, 64>(__VA_ARGS__) : FN<false, 64>(__VA_ARGS__); break;                     \
+    }
+
+// the chains (the number of live chains is read on the device: slots beyond it exit at once)
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
-    launch_correct_mode<false>(m, n_cand, cb, split, params, stream);
-    launch_correct_mode<true>(m, n_cand, cb, split, params, stream);
+    const bool cp = m.flags & MISTI_CPFIT;
+    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, stream)
     return hipGetLastError();
 }
 
@@ -1727,19 +1769,21 @@ int64_t trunk_capacity(int64_t n_cand) {
     return off ? 0 : n_cand / TRUNK_MIN_SHARE;
 }
 
+// trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
-                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag, hipStream_t stream) {
+                           const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
-    if (cb.trunk_cap > 0)
-        hipLaunchKernelGGL(trunk_kernel, dim3((unsigned)cb.trunk_cap), dim3(64), (128 + 2 * (size_t)(m.numT + 1)) * sizeof(double), stream,
-                           m, n_cand, params, cb);
+    const bool cp = m.flags & MISTI_CPFIT;
+    MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, stream)
+    const int n_inline = (n_rep > 0 && n_rep <= LLK_INLINE_MAX) ? (int)n_rep : 0;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    if (m.flags & MISTI_CPFIT)
+    if (cp)
         hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk);
     else
         hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag);
+                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk);
     return hipGetLastError();
 }
 
