@@ -63,8 +63,8 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--workload", default="config2", help="config2 (headline) | config3 | config4 | config5")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,7 +81,8 @@ def algorithmic_bytes(w, n_rep):
     correction: one chain per distinct parameter vector, computed up to the largest split index of
                 its members: 8P in; per interval 16 B of rates + 48 B of pair state out;
     spectrum:   per candidate split 8 + params 8P in, its share of the chain 16 B per two-population
-                interval + 48 B state, JAFS 56 + status 4 out;
+                interval + 48 B state, JAFS 56 + status 4 out (+ one trunk record of 1 056 B when chains are
+                shared; the trunk launch itself writes one record per chain and interval);
     llk:        JAFS 56 + status 4 in (the replicate table is shared), 8 per replicate out."""
     P, n = w.n_param, w.n_cand
     s_int = np.floor(w.split_time).astype(int)
@@ -93,6 +94,8 @@ def algorithmic_bytes(w, n_rep):
             chains[row] = max(chains.get(row, 0), int(s))
     correct = sum(8 * P + 64 * L for L in chains.values())
     spectrum = int((8 + 8 * P + 16 * s_int + 48 + 60).sum())
+    if len(chains) * 8 <= n:                                  # TRUNK_MIN_SHARE (misti_consts.h)
+        spectrum += 1056 * n + sum(1056 * (L + 1) for L in chains.values())
     return {"correct": correct, "spectrum": spectrum, "llk": n * (60 + 8 * n_rep), "n_chains": len(chains)}
 
 
