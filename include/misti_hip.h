@@ -191,10 +191,11 @@ int misti_forward_rates_dev(misti_ctx* ctx, int64_t n_cand, const double* d_spli
                             double* d_lh, double* d_pr, int32_t* d_status);
 
 /* ---- measurement ----------------------------------------------------------- */
-/* When enabled, every kernel launch of this context is bracketed by HIP events
+/* When enabled, the stages of every batch of this context are bracketed by HIP events
  * on its stream.  misti_kernel_times returns the accumulated device time (ms)
- * and launch counts since the last reset: [0] lambda-correction kernel,
- * [1] spectrum kernel, [2] replicate (llk) kernel. */
+ * and batch counts since the last reset: [0] prepare + chain discovery + lambda-correction
+ * of the chains, [1] trunks/tails + spectrum kernel (incl. the replicate epilogue for <= 8
+ * replicates), [2] separate replicate (llk) kernel (more than 8 replicates, misti_llk_dev). */
 int misti_enable_timing(misti_ctx* ctx, int on);
 int misti_kernel_times(misti_ctx* ctx, double ms[3], int64_t launches[3], int reset);
 
