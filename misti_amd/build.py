@@ -34,6 +34,8 @@ def build(force=False, verbose=False, extra=()):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
     cmd += list(extra)
+    if os.environ.get("MISTI_STAMP2"):         # diagnostic build: stage cycle counts of the spectrum kernel in place of the spectrum
+        cmd += ["-DMISTI_STAMP2=1"]
     if os.environ.get("MISTI_STAMP"):          # diagnostic build: per-section cycle stamps in the correction kernel
         cmd += ["-DMISTI_STAMP=1"]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]

@@ -175,7 +175,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const size_t tsize = misti::chain_table_size(n_cand);
     const size_t ntr = (size_t)misti::trunk_capacity(n_cand);
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
-    const size_t i32_n = 2 + 3 * tsize + 6 * nc + ntr;      // n_chains | table, slot_chain, slot_len | slot_of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
+    const size_t i32_n = 2 + 3 * tsize + 7 * nc + ntr;      // n_chains | table, slot_chain, slot_len | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
     HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
     HIP_TRY(c->ws_order.reserve(nc * sizeof(int32_t)));
@@ -192,7 +192,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         int32_t* q = c->ws_chain_i32.as<int32_t>();
         cb.n_chains = q; q += 2;
         cb.table = q; q += tsize; cb.slot_chain = q; q += tsize; cb.slot_len = q; q += tsize;
-        cb.slot_of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
+        cb.slot_of = q; q += nc; cb.of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
         cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc;
         cb.trunk_ok = q;
         cb.tmask = (uint32_t)(tsize - 1);
@@ -278,6 +278,16 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         for (int cl = 0; cl < 7; ++cl) {
             for (int s = 0; s < 64; ++s) dt.jaf[cl][s] = s < misti::NS2 ? t.jaf[s][cl] : 0;
             for (int s = 0; s < misti::NS1; ++s) dt.jaf1[cl][s] = t.jaf1[s][cl];
+            for (int s = 0; s < misti::NS2; ++s) {
+                const int wgt = t.jaf[s][cl];
+                if (wgt < 0 || wgt > 7) throw std::runtime_error("spectrum weight out of range");
+                for (int b = 0; b < 3; ++b) if ((wgt >> b) & 1) dt.jaf_bits[cl][b] |= 1ull << s;
+            }
+            for (int s = 0; s < misti::NS1; ++s) {
+                const int wgt = t.jaf1[s][cl];
+                if (wgt < 0 || wgt > 7) throw std::runtime_error("spectrum weight out of range");
+                dt.jaf1_bits[cl] |= (unsigned)wgt << (3 * s);
+            }
         }
         std::memcpy(dt.grp_lo, t.grp_lo, sizeof dt.grp_lo);
         std::memcpy(dt.grp_hi, t.grp_hi, sizeof dt.grp_hi);

@@ -17,6 +17,8 @@ struct DevTables {
     int dcnt[4][64];         // exit-rate multiplicities of the state (diagonal = -sum dcnt*rate)
     int jaf[7][64];          // class-major StateToJAF
     int jaf1[7][NS1];
+    unsigned long long jaf_bits[7][3];   // the same weights (0..7) as bit planes over the 44 states: one 24-byte load per class
+    unsigned int jaf1_bits[7];           // one-population weights, 3 bits per state
     int grp_lo[NS1], grp_hi[NS1];
     int anc_n[2], anc_dst[2], anc_src[2][8];
     int pulse_n[2][64];
@@ -50,6 +52,7 @@ struct ChainBufs {
     int32_t* slot_chain;    // [tsize] slot -> chain
     int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
     int32_t* slot_of;       // [n] candidate -> slot
+    int32_t* of;            // [n] candidate -> chain, resolved by the idle blocks of the chain launch
     int32_t* chain_slot;    // [n] chain -> slot
     int32_t* rep;           // [n] chain -> a member candidate (its parameters)
     uint32_t tmask;         // tsize - 1 (tsize a power of two >= 2 n)
@@ -66,7 +69,7 @@ struct ChainBufs {
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
 };
 
-__device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.slot_chain[cb.slot_of[cand]]; }
+__device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.of[cand]; }
 __device__ __forceinline__ int chain_len(const ChainBufs& cb, int64_t ch) { return cb.slot_len[cb.chain_slot[ch]]; }
 
 // Replicate epilogue fused into the spectrum kernel up to this many replicates (one launch less per batch).

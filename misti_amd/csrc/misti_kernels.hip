@@ -52,7 +52,12 @@ constexpr int JACOBI_MAX = 600;
 // ---------------------------------------------------------------- helpers ----
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ double bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+// broadcast from a WAVE-UNIFORM source lane: scalar readlane, no LDS crossbar round trip
+__device__ __forceinline__ double bcast(double v, int src_lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
 
 // The correction kernel packs GROUP (8, 16, 32 or 64) lanes per candidate, 6 of which carry the
 // residual evaluations (3 forward-difference points x 2 genomes): 8 ... 1 candidates per wavefront,
@@ -1095,6 +1100,11 @@ template <bool CPFIT, int GROUP>
 __global__ __launch_bounds__(64)
 void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
     extern __shared__ double lds[];
+    {   // candidate -> chain, once, by blocks that mostly have nothing else to do (the launch has one block per
+        // 64/GROUP candidates, the chains occupy the first few): later kernels read it without the slot indirection
+        const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
+    }
     correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds);
 }
 
@@ -1259,14 +1269,18 @@ __device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevMode
 
 // Smooth (:380-405) on a wave's rates in LDS: time-weighted mean of lc over runs of constant lh,
 // t < bound; a run is cut at `bound` (the candidate's split index).
-__device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, double* lcb, int lane, int bound) {
+__device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, double* lcb, int lane, int lo, int bound) {
+    // intervals lo <= t < bound are smoothed (lo > 0: the caller does not need the others); wave-uniform skip of
+    // the 64-interval slices outside that range
     double sm[SMOOTH_REPS][2];   // intervals rep*64+lane, both genomes
 #pragma unroll
     for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
+        sm[rep][0] = sm[rep][1] = 0.0;
+        if (rep * 64 >= bound || rep * 64 + 63 < lo) continue;
         int t = rep * 64 + lane;
         for (int k = 0; k < 2; ++k) {
             double v = 0.0;
-            if (t < bound) {
+            if (t >= lo && t < bound) {
                 int a = m.run_start[k * m.numT + t];
                 int b = m.run_end[k * m.numT + t];
                 if (b > bound) b = bound;
@@ -1281,7 +1295,7 @@ __device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, d
 #pragma unroll
     for (int rep = 0; rep < SMOOTH_REPS; ++rep) {
         int t = rep * 64 + lane;
-        if (t < bound) { lcb[2 * t] = sm[rep][0]; lcb[2 * t + 1] = sm[rep][1]; }
+        if (t >= lo && t < bound) { lcb[2 * t] = sm[rep][0]; lcb[2 * t + 1] = sm[rep][1]; }
     }
     lds_fence();
 }
@@ -1320,7 +1334,7 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
     for (int i = lane; i < 2 * (m.numT + 1); i += 64) lcb[i] = ((i >> 1) < Lt) ? lc_ch[i] : 0.0;
     lds_fence();
-    if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, Lt);
+    if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, 0, Lt);
     TwoPopRow R;
     R.load(lane);
     double x = (lane == 2) ? 1.0 : 0.0;
@@ -1354,7 +1368,7 @@ void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, const double* __restr
 // lane = state of the 44-state chain afterwards.
 // LDS per wave (doubles): xbuf[128] (re | im) | lc[2*(numT0+1)]
 template <bool CPFIT>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64)
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 4)      // 4 waves per SIMD: a 4 096-candidate batch is resident in one round
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
                      double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out,
@@ -1364,6 +1378,13 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     const int wave = threadIdx.x >> 6;
     const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (slot >= n_cand) return;
+#ifdef MISTI_STAMP2
+    long long s_[8];
+#define KSTAMP(i) s_[i] = clock64();
+#else
+#define KSTAMP(i)
+#endif
+    KSTAMP(0)
     const int64_t cand = order[slot];
     const int lc_rows = m.numT + 1;
     double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
@@ -1411,6 +1432,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             }
         return;
     }
+    KSTAMP(1)
     for (int i = lane; i < 2 * lc_rows; i += 64) {
         const int t = i >> 1;
         lcb[i] = (t < nfull) ? lc_ch[i] : (t == nfull && G.ins >= 0) ? cb.tail_lc[2 * cand + (i & 1)] : 0.0;
@@ -1425,6 +1447,28 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
         if (diag_out && lane == 0) diag_out[cand] = (m.flags & MISTI_TRUE_EPS) ? 0.0 : mx;
     }
+    // ---- where this candidate leaves the trunk of its chain --------------------------------
+    int t0 = 0;
+    const bool use_trunk = trunk_active(cb, n_cand);
+    int smooth_from = 0;
+    if (use_trunk) {
+        // first interval whose rates depend on this candidate's split: the start of the smoothing
+        // run (of either genome) that the split cuts; the shortened interval of a fractional split
+        int t_own = nfull;
+        if (m.flags & MISTI_SMOOTH) {
+            if (G.ins >= 0) {
+                t_own = min(m.run_start[G.ins], m.run_start[m.numT + G.ins]);
+            } else if (G.split > 0) {
+                for (int k = 0; k < 2; ++k)
+                    if (m.run_end[k * m.numT + G.split - 1] > G.split) t_own = min(t_own, m.run_start[k * m.numT + G.split - 1]);
+            }
+        }
+        t0 = min(t_own, cb.trunk_ok[ch]);
+        // smoothed rates below t0 are only needed for the optional lc output: skip them otherwise (a run that
+        // reaches back below t_own still reads the unsmoothed values there: smoothing writes after all reads)
+        if (t0 == t_own && !lc_o) smooth_from = t_own;
+    }
+    KSTAMP(2)
     {
         // ---- post-split rates (:355-376); nc is a probability used as a log ----
         const double* stt = (G.ins >= 0) ? cb.tail_state + 6 * cand : tr_ch + 6 * nfull;    // pair state at the split
@@ -1461,13 +1505,16 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             }
         }
         lds_fence();
+        KSTAMP(3)
         // ---- Smooth (:380-405): time-weighted mean of lc over runs of constant lh, t < split
-        if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, G.split);
+        if (m.flags & MISTI_SMOOTH) smooth_rates(m, G, lcb, lane, smooth_from, G.split);
         for (int i = lane; i < 2 * G.numT; i += 64) { double v = lcb[i]; if (!(v == v)) status = MISTI_NUMERIC; }
         status = __any(status != MISTI_OK) ? MISTI_NUMERIC : MISTI_OK;
         if (lc_o) for (int i = lane; i < 2 * lc_rows; i += 64) lc_o[i] = (i < 2 * G.numT) ? lcb[i] : 0.0;
     }
-    double jafs[7] = {0, 0, 0, 0, 0, 0, 0};
+    double jn = NAN;                      // lane c < 7: normalised expected spectrum, class c
+    KSTAMP(4)
+    KSTAMP(5) KSTAMP(6) KSTAMP(7)
 
     if (status == MISTI_OK) {
         // ---- expected spectrum, two-population part (:467-506) ----------------
@@ -1476,20 +1523,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         const bool live = R.live;
         double x = (lane == 2) ? 1.0 : 0.0;
         double w_pre = 0.0, w_post = 0.0;          // occupation integrals before / from the sample date
-        int t0 = 0;
-        if (trunk_active(cb, n_cand)) {
-            // first interval whose rates depend on this candidate's split: the start of the smoothing
-            // run (of either genome) that the split cuts; the shortened interval of a fractional split
-            int t_own = nfull;
-            if (m.flags & MISTI_SMOOTH) {
-                if (G.ins >= 0) {
-                    t_own = min(m.run_start[G.ins], m.run_start[m.numT + G.ins]);
-                } else if (G.split > 0) {
-                    for (int k = 0; k < 2; ++k)
-                        if (m.run_end[k * m.numT + G.split - 1] > G.split) t_own = min(t_own, m.run_start[k * m.numT + G.split - 1]);
-                }
-            }
-            t0 = min(t_own, cb.trunk_ok[ch]);
+        if (use_trunk) {
             const double* r = cb.trunk + (ch * (int64_t)m.numT + t0) * TRUNK_REC;
             if (live) { x = r[lane]; w_pre = r[NS2 + lane]; w_post = r[2 * NS2 + lane]; }
         }
@@ -1499,14 +1533,19 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             const int st = twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post);
             if (st != MISTI_OK) { status = st; break; }
         }
+        KSTAMP(5)
         if (status == MISTI_OK) {
             // two-population share of the spectrum: lanes 0..6 each sum one class
             xbuf[lane] = live ? w_post : 0.0; lds_fence();
             double jp = 0.0;
-            if (lane < 7) for (int i = 0; i < NS2; ++i) jp += (double)c_tab.jaf[lane][i] * xbuf[i];
+            // weights as bit planes (same products, same order as a table walk; one 24-byte load per class)
+            unsigned long long b0 = 0, b1 = 0, b2 = 0;
+            if (lane < 7) { b0 = c_tab.jaf_bits[lane][0]; b1 = c_tab.jaf_bits[lane][1]; b2 = c_tab.jaf_bits[lane][2]; }
+            auto weight = [&](int i) { return (double)(int)(((b0 >> i) & 1) | (((b1 >> i) & 1) << 1) | (((b2 >> i) & 1) << 2)); };
+            if (lane < 7) for (int i = 0; i < NS2; ++i) jp += weight(i) * xbuf[i];
             lds_fence();
             xbuf[lane] = live ? w_pre : 0.0; lds_fence();
-            if (lane < 2) for (int i = 0; i < NS2; ++i) jp += (double)c_tab.jaf[lane][i] * xbuf[i];
+            if (lane < 2) for (int i = 0; i < NS2; ++i) jp += weight(i) * xbuf[i];
             lds_fence();
             // CollapsePops (:518-528)
             xbuf[lane] = live ? x : 0.0; lds_fence();
@@ -1515,6 +1554,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             lds_fence();
             double P8[NS1];
             for (int i = 0; i < NS1; ++i) P8[i] = bcast(c8, i);
+            KSTAMP(6)
             // ---- one-population part: Kingman coalescent in rescaled time --------
             // P(s) = V1 e^-s + V3 e^-3s + V6 e^-6s, s = int lc dt; occupation integral of
             // interval t is (1/lc_t) * int_{S_t}^{S_t+tau_t} P(s) ds (OnePopulation.py:153-178,
@@ -1557,31 +1597,35 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             for (int o = 32; o > 0; o >>= 1) { G1 += __shfl_xor(G1, o, 64); G3 += __shfl_xor(G3, o, 64); G6 += __shfl_xor(G6, o, 64); }
             // assemble: lane c < 7 holds class c
             double j1 = 0.0;
-            if (lane < 7) for (int i = 0; i < NS1; ++i) j1 += (double)c_tab.jaf1[lane][i] * (V1[i] * G1 + V3[i] * G3 + V6[i] * G6);
+            const unsigned w1 = lane < 7 ? c_tab.jaf1_bits[lane] : 0u;
+            if (lane < 7) for (int i = 0; i < NS1; ++i) j1 += (double)(int)((w1 >> (3 * i)) & 7u) * (V1[i] * G1 + V3[i] * G3 + V6[i] * G6);
             double jc = jp + j1;
             double tot = 0.0;
-            for (int c = 0; c < 7; ++c) { jafs[c] = bcast(jc, c); tot += jafs[c]; }   // :583-584
-            for (int c = 0; c < 7; ++c) jafs[c] /= tot;
-            for (int c = 0; c < 7; ++c) if (!(jafs[c] == jafs[c])) status = MISTI_NUMERIC;
+            for (int c = 0; c < 7; ++c) tot += bcast(jc, c);                         // :583-584
+            jn = jc / tot;                                                           // lane c < 7: class c, normalised
+            if (__any(lane < 7 && !(jn == jn))) status = MISTI_NUMERIC;
         }
     }
+    KSTAMP(7)
     // ---- outputs ------------------------------------------------------------
     if (lane == 0) status_out[cand] = status;
     if (lane < 7) {
-        double v = NAN;
-        for (int c = 0; c < 7; ++c) if (lane == c) v = jafs[c];
-        jafs_out[cand * 7 + lane] = (status == MISTI_OK) ? v : NAN;
+        jafs_out[cand * 7 + lane] = (status == MISTI_OK) ? jn : NAN;
+#ifdef MISTI_STAMP2
+        jafs_out[cand * 7 + lane] = (double)(s_[lane + 1] - s_[lane]);
+#endif
     }
     // ---- replicate epilogue for small replicate counts (:600-609): lane r = replicate r ----
-    if (lane < n_inline) {
-        double out = -INFINITY;
-        if (status == MISTI_OK) {
-            const int unfolded = (m.flags & MISTI_UNFOLDED) ? 1 : 0;
-            double lj[7];
-            for (int i = 0; i < 7; ++i) lj[i] = log_class(jafs, i, unfolded);
-            out = llk_of(jsfs + (int64_t)lane * 8, consts[lane], lj, unfolded);
-        }
-        llk_out[cand * n_inline + lane] = out;
+    if (n_inline > 0) {
+        const int unfolded = (m.flags & MISTI_UNFOLDED) ? 1 : 0;
+        // log of class `lane` (folded: classes 0+6, 1+5, 2+4, 3), the same expression as log_class()
+        const double mirror = __shfl(jn, lane < 7 ? 6 - lane : lane, 64);
+        double lcl = 0.0;
+        if (lane < 7 && status == MISTI_OK) lcl = unfolded ? log(jn) : (lane < 3 ? log(jn + mirror) : (lane == 3 ? log(jn) : 0.0));
+        double lj[7];
+        for (int i = 0; i < 7; ++i) lj[i] = bcast(lcl, i);
+        if (lane < n_inline)
+            llk_out[cand * n_inline + lane] = (status == MISTI_OK) ? llk_of(jsfs + (int64_t)lane * 8, consts[lane], lj, unfolded) : -INFINITY;
     }
 }
 
