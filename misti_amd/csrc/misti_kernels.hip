@@ -48,6 +48,7 @@ __constant__ double c_inv[INV_TABLE];   // c_inv[k] = 1/k: series terms divide b
 //    unless migration is strong in both directions).  Cost is independent of q.
 constexpr double Q_SWITCH = 96.0;
 constexpr int JACOBI_MAX = 600;
+constexpr long long FOLLOW_SPIN_LIMIT = 1LL << 22;   // polls (~1 us each) before a following trunk wave gives up
 
 // ---------------------------------------------------------------- helpers ----
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -851,7 +852,7 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 template <bool CPFIT, int GROUP, bool TAIL>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
-                  int64_t block, double* lds) {
+                  int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr) {
     const int lane = lane_id();
     const int sub = lane & (GROUP - 1);
     const int64_t slot = (block * (64 / GROUP)) + (lane / GROUP);
@@ -872,7 +873,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         for (int i = lane; i < nt; i += 64) lds[i] = m.times[i];
         for (int i = lane; i < nl; i += 64) lds[nt + i] = m.lh[i];
     }
-    __syncthreads();
+    lds_fence();                                   // staged and read by this wavefront only
     if (slot >= n_live) return;
     const int64_t cand = TAIL ? slot : (int64_t)cb.rep[slot];      // whose parameters
     const double* par = params ? params + cand * m.n_param : nullptr;
@@ -928,6 +929,12 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         if (sub == 0) {
             double* r = tr_w + 6 * (t + 1);
             r[0] = ps.p[0][0]; r[1] = ps.p[1][0]; r[2] = ps.p[0][1]; r[3] = ps.p[1][1]; r[4] = ps.p[0][2]; r[5] = ps.p[1][2];
+        }
+        if (!TAIL && lc_sh) {
+            // hand the interval to the trunk wave of this workgroup (correct_follow_kernel): rates, then the count
+            if (sub == 0) { lc_sh[2 * t] = lc0; lc_sh[2 * t + 1] = lc1; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (sub == 0) flags[0] = t + 1;
         }
         ++t;
         return true;
@@ -1267,6 +1274,13 @@ __device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevMode
     return MISTI_OK;
 }
 
+// time-weighted mean of genome k's rates over intervals [a, b) (one smoothing run, :392-403)
+__device__ __forceinline__ double run_mean(const double* lc, int k, int a, int b, const Grid& G) {
+    double acc = 0.0, tt = 0.0;
+    for (int j = a; j < b; ++j) { double Tj = G.T(j); acc += lc[2 * j + k] * Tj; tt += Tj; }
+    return acc / tt;
+}
+
 // Smooth (:380-405) on a wave's rates in LDS: time-weighted mean of lc over runs of constant lh,
 // t < bound; a run is cut at `bound` (the candidate's split index).
 __device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, double* lcb, int lane, int lo, int bound) {
@@ -1284,9 +1298,7 @@ __device__ __forceinline__ void smooth_rates(const DevModel& m, const Grid& G, d
                 int a = m.run_start[k * m.numT + t];
                 int b = m.run_end[k * m.numT + t];
                 if (b > bound) b = bound;
-                double acc = 0.0, tt = 0.0;
-                for (int j = a; j < b; ++j) { double Tj = G.T(j); acc += lcb[2 * j + k] * Tj; tt += Tj; }
-                v = acc / tt;
+                v = run_mean(lcb, k, a, b, G);
             }
             sm[rep][k] = v;
         }
@@ -1351,16 +1363,100 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     if (lane == 0) cb.trunk_ok[ch] = ok;
 }
 
+// The trunk as a FOLLOWER of its chain: second wavefront of the chain's workgroup
+// (correct_follow_kernel).  The chain wave hands over each corrected interval through LDS (rates,
+// then a count); this wave propagates interval t as soon as the smoothing runs containing t are
+// complete, so the trunk is finished almost when the chain is - its ~0.3 ms leave the critical
+// path of a batch.  Same records, same arithmetic as trunk_body (run_mean + twopop_interval).  Both
+// waves are resident by construction (one workgroup), and the wait is bounded: a follower that gives up
+// publishes the prefix it has, which is all the candidate kernel relies on (trunk_ok).
+__device__ __forceinline__
+void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ params, const ChainBufs& cb, int64_t ch, double* lds,
+                  const double* lc_sh, volatile int* flags) {
+    const int lane = lane_id();
+    if (!trunk_active(cb, n_cand) || ch >= cb.n_chains[0]) return;
+    double* xbuf = lds;
+    double* lcb = lds + 128;
+    const int len = chain_len(cb, ch);
+    const double* par = params ? params + (int64_t)cb.rep[ch] * m.n_param : nullptr;
+    Grid G;
+    G.times = m.times; G.lh = m.lh; G.numT0 = m.numT; G.numT = m.numT; G.split = len; G.ins = -1; G.frac = 0.0;
+    Model mod{&m, par, len, {0, 0, 0, 0}};
+    mod.cache();
+    for (int i = lane; i < 2 * (m.numT + 1); i += 64) lcb[i] = 0.0;
+    lds_fence();
+    TwoPopRow R;
+    R.load(lane);
+    double x = (lane == 2) ? 1.0 : 0.0;
+    double w_pre = 0.0, w_post = 0.0;
+    double* rec = cb.trunk + ch * (int64_t)m.numT * TRUNK_REC;
+    const bool smooth = m.flags & MISTI_SMOOTH;
+    int ok = 0, have = 0, done = 0;
+    long long spins = 0;
+    for (int t = 0; t < m.numT; ++t) {
+        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = x; r[NS2 + lane] = w_pre; r[2 * NS2 + lane] = w_post; }
+        ok = t;
+        if (t >= len) break;
+        int a0 = t, b0 = t + 1, a1 = t, b1 = t + 1;
+        if (smooth) { a0 = m.run_start[t]; b0 = m.run_end[t]; a1 = m.run_start[m.numT + t]; b1 = m.run_end[m.numT + t]; }
+        int need = b0 > b1 ? b0 : b1;
+        if (need > len) need = len;
+        while (have < need && !done) {
+            done = flags[1];                       // read `done` first: the count read after it is then final
+            have = flags[0];
+            if (have >= need || done) break;
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > FOLLOW_SPIN_LIMIT) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (have < need && !done) break;           // gave up waiting: keep the prefix
+        const int cut = have >= need ? len : have; // the chain ended early (failure): runs are cut where it ended
+        if (t >= cut) break;
+        if (b0 > cut) b0 = cut;
+        if (b1 > cut) b1 = cut;
+        const double l0 = smooth ? run_mean(lc_sh, 0, a0, b0, G) : lc_sh[2 * t];
+        const double l1 = smooth ? run_mean(lc_sh, 1, a1, b1, G) : lc_sh[2 * t + 1];
+        if (lane == 0) { lcb[2 * t] = l0; lcb[2 * t + 1] = l1; }
+        lds_fence();
+        if (t == m.sample_date) ancient_project(xbuf, lane, x);
+        if (twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post) != MISTI_OK) break;
+    }
+    if (lane == 0) cb.trunk_ok[ch] = ok;
+}
+
+// Kernel 1 with the trunk following: 128-thread workgroups, wave 0 = the chain (one chain per wave),
+// wave 1 = its trunk.  LDS (doubles): kernel-1 staging [3 numT] | trunk xbuf [128] + rates [2 (numT+1)] |
+// hand-over rates [2 numT] | count, done flag.
+template <bool CPFIT>
+__global__ __launch_bounds__(128)
+void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+    extern __shared__ double lds[];
+    double* tk = lds + 3 * (size_t)m.numT;
+    double* lc_sh = tk + 128 + 2 * (size_t)(m.numT + 1);
+    volatile int* flags = (volatile int*)(lc_sh + 2 * (size_t)m.numT);
+    if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;          // candidate -> chain (see correct_kernel)
+        if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
+        correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, lc_sh, flags);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (threadIdx.x == 0) flags[1] = 1;                                  // whatever way the chain ended
+    } else {
+        trunk_follow(m, n_items, params, cb, (int64_t)blockIdx.x, tk, lc_sh, flags);
+    }
+}
+
 // Everything that waits for the chains and that the candidate kernel waits for, in ONE launch: the
 // trunks (blocks below trunk_cap, dispatched first: they are the long ones) and the tails of the
 // lambda-correction (the shortened last interval of candidates with a fractional split).  A launch
 // costs a queue round trip, which is what limits the rate when many batches are in flight.
 template <bool CPFIT, int GROUP>
 __global__ __launch_bounds__(64)
-void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, int64_t trunk_blocks, const double* __restrict__ split_time, const double* __restrict__ params) {
     extern __shared__ double lds[];
-    if ((int64_t)blockIdx.x < cb.trunk_cap) trunk_body(m, n_cand, params, cb, (int64_t)blockIdx.x, lds);
-    else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - cb.trunk_cap, lds);
+    if ((int64_t)blockIdx.x < trunk_blocks) trunk_body(m, n_cand, params, cb, (int64_t)blockIdx.x, lds);
+    else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - trunk_blocks, lds);
 }
 
 // Kernel 2: post-split rates (:355-376), Smooth (:380-405) and the expected joint spectrum
@@ -1780,13 +1876,22 @@ static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs&
     hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params);
 }
 
+// One chain per wavefront and a trunk to build: the trunk follows its chain inside the chain launch
+// (correct_follow_kernel) instead of running after it.  MISTI_NO_FOLLOW=1 keeps it in the post launch.
+static bool trunk_follows(int64_t n_cand, const ChainBufs& cb) {
+    const char* e = getenv("MISTI_NO_FOLLOW");
+    const bool off = e && e[0] && e[0] != '0';
+    return !off && cb.trunk_cap > 0 && correct_cands_per_wave(n_cand) == 1;
+}
+
 template <bool CPFIT, int GROUP>
 static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
     const int per_wave = 64 / GROUP;
-    dim3 grid((unsigned)(cb.trunk_cap + (n_cand + per_wave - 1) / per_wave));
+    const int64_t trunk_blocks = trunk_follows(n_cand, cb) ? 0 : cb.trunk_cap;
+    dim3 grid((unsigned)(trunk_blocks + (n_cand + per_wave - 1) / per_wave));
     size_t lds = correct_lds_bytes(m.numT);
     if (trunk_lds_bytes(m.numT) > lds) lds = trunk_lds_bytes(m.numT);
-    hipLaunchKernelGGL((post_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, cb, split, params);
+    hipLaunchKernelGGL((post_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, cb, trunk_blocks, split, params);
 }
 
 #define MISTI_DISPATCH_GROUP(FN, ...)                                                                   \
@@ -1801,6 +1906,12 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
+    if (trunk_follows(n_cand, cb)) {
+        const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT) * sizeof(double) + 4 * sizeof(int);
+        if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
+        else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
+        return hipGetLastError();
+    }
     MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, stream)
     return hipGetLastError();
 }
