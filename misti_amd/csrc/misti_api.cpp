@@ -71,6 +71,8 @@ struct misti_ctx {
     DevBuf ws_order;                    // dispatch order (heaviest candidates first)
     DevBuf ws_diag;                     // per candidate: largest corrected rate x interval length of the last batch
     int64_t diag_n = 0;
+    int32_t* hint_host = nullptr;       // pinned, device-visible: {chains, candidates} of the last batch (a launch-shape hint only)
+    int32_t* hint_dev = nullptr;
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
@@ -198,7 +200,21 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.tmask = (uint32_t)(tsize - 1);
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
         cb.trunk_cap = (int64_t)ntr;
+        cb.hint = c->hint_dev;
     }
+    // launch shape of kernel 1 from the number of chains the previous batch of this size had (the count lives on
+    // the device; the kernel drops it into pinned memory, no synchronisation).  A stale hint costs speed only.
+    int64_t est_chains = n_cand;
+    if (c->hint_host) {
+        const volatile int32_t* h = c->hint_host;
+        const int32_t h_chains = h[0], h_cand = h[1];
+        if (h_cand == (int32_t)n_cand && h_chains > 0 && h_chains <= n_cand) est_chains = h_chains;
+    }
+    // chains per wavefront: packed (up to 8) when the batch is large - fewer instructions in total, which is what
+    // counts when batches overlap - unless it is known to collapse into a few long chains (pure latency: one chain
+    // per wave and the trunk following it)
+    const int cpw_chains = est_chains <= 256 ? 1 : misti::correct_cands_per_wave(n_cand);
+    const bool follow = misti::trunk_follows(cpw_chains, (int64_t)ntr);
     // a batch is five launches (six with more than LLK_INLINE_MAX replicates): prepare | discover | chains |
     // trunks + tails | candidates (+ replicate epilogue).  Few launches matter when many batches are in flight.
     int32_t* d_order = c->ws_order.as<int32_t>();
@@ -208,14 +224,14 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (int r = record_begin(c, 0, &a, &b)) return r;
     HIP_TRY(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream));
     HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->stream));
-    HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, c->stream));
+    HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, c->stream));
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
     HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                   n_rep, d_jsfs, d_consts, d_llk, c->stream));
+                                   n_rep, d_jsfs, d_consts, d_llk, follow, c->stream));
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {
@@ -320,6 +336,10 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
 
         const int numT = model->numT;
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        if (hipHostMalloc((void**)&c->hint_host, 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
+            c->hint_host[0] = c->hint_host[1] = 0;
+            if (hipHostGetDevicePointer((void**)&c->hint_dev, c->hint_host, 0) != hipSuccess) c->hint_dev = nullptr;
+        } else { (void)hipGetLastError(); c->hint_host = nullptr; }
         c->stream = c->own_stream;
         std::vector<double> f64((size_t)(numT - 1) + 2 * (size_t)numT);
         std::memcpy(f64.data(), model->times, sizeof(double) * (numT - 1));
@@ -365,6 +385,7 @@ int misti_destroy(misti_ctx* c) {
     for (int w = 0; w < 3; ++w)
         for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->hint_host) (void)hipHostFree(c->hint_host);
     delete c;
     return 0;
 }

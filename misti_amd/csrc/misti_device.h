@@ -67,6 +67,7 @@ struct ChainBufs {
     double* trunk;          // [trunk_cap][numT][TRUNK_REC] per chain: 44-state vector + occupation integrals before interval t
     int32_t* trunk_ok;      // [trunk_cap] per chain: last valid record
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
+    int32_t* hint;          // host-pinned [2] or NULL: {chains, candidates} of this batch, read by the host before the NEXT one
 };
 
 __device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.of[cand]; }
@@ -82,10 +83,13 @@ uint32_t chain_table_size(int64_t n_cand);
 hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
                           int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream);
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream);
+int correct_cands_per_wave(int64_t n_items);
+bool trunk_follows(int cpw_chains, int64_t trunk_cap);
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
+                          int cpw, bool follow, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, hipStream_t stream);
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);

@@ -1111,6 +1111,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
         // 64/GROUP candidates, the chains occupy the first few): later kernels read it without the slot indirection
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
+        if (i == 0 && cb.hint) { cb.hint[0] = cb.n_chains[0]; cb.hint[1] = (int32_t)n_items; }   // to the host, for the next batch's launch shape
     }
     correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds);
 }
@@ -1439,6 +1440,7 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     if (threadIdx.x < 64) {
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;          // candidate -> chain (see correct_kernel)
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
+        if (i == 0 && cb.hint) { cb.hint[0] = cb.n_chains[0]; cb.hint[1] = (int32_t)n_items; }
         correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, lc_sh, flags);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (threadIdx.x == 0) flags[1] = 1;                                  // whatever way the chain ended
@@ -1878,16 +1880,16 @@ static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs&
 
 // One chain per wavefront and a trunk to build: the trunk follows its chain inside the chain launch
 // (correct_follow_kernel) instead of running after it.  MISTI_NO_FOLLOW=1 keeps it in the post launch.
-static bool trunk_follows(int64_t n_cand, const ChainBufs& cb) {
+bool trunk_follows(int cpw_chains, int64_t trunk_cap) {
     const char* e = getenv("MISTI_NO_FOLLOW");
     const bool off = e && e[0] && e[0] != '0';
-    return !off && cb.trunk_cap > 0 && correct_cands_per_wave(n_cand) == 1;
+    return !off && trunk_cap > 0 && cpw_chains == 1;
 }
 
 template <bool CPFIT, int GROUP>
-static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, bool follow, hipStream_t stream) {
     const int per_wave = 64 / GROUP;
-    const int64_t trunk_blocks = trunk_follows(n_cand, cb) ? 0 : cb.trunk_cap;
+    const int64_t trunk_blocks = follow ? 0 : cb.trunk_cap;
     dim3 grid((unsigned)(trunk_blocks + (n_cand + per_wave - 1) / per_wave));
     size_t lds = correct_lds_bytes(m.numT);
     if (trunk_lds_bytes(m.numT) > lds) lds = trunk_lds_bytes(m.numT);
@@ -1895,7 +1897,7 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 }
 
 #define MISTI_DISPATCH_GROUP(FN, ...)                                                                   \
-    switch (correct_cands_per_wave(n_cand)) {                                                            \
+    switch (cpw) {                                                                                       \
         case 8: cp ? FN<true, 8>(__VA_ARGS__) : FN<false, 8>(__VA_ARGS__); break;                        \
         case 4: cp ? FN<true, 16>(__VA_ARGS__) : FN<false, 16>(__VA_ARGS__); break;                      \
         case 2: cp ? FN<true, 32>(__VA_ARGS__) : FN<false, 32>(__VA_ARGS__); break;                      \
@@ -1903,10 +1905,12 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
     }
 
 // the chains (the number of live chains is read on the device: slots beyond it exit at once)
-hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+// cpw: chains per wavefront, chosen by the caller from the expected number of chains
+hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
+                          int cpw, bool follow, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
-    if (trunk_follows(n_cand, cb)) {
+    if (follow) {
         const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT) * sizeof(double) + 4 * sizeof(int);
         if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
         else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
@@ -1927,10 +1931,11 @@ int64_t trunk_capacity(int64_t n_cand) {
 // trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, hipStream_t stream) {
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
-    MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, stream)
+    const int cpw = correct_cands_per_wave(n_cand);              // tails: one item per candidate
+    MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream)
     const int n_inline = (n_rep > 0 && n_rep <= LLK_INLINE_MAX) ? (int)n_rep : 0;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (cp)

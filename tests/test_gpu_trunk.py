@@ -106,3 +106,30 @@ def test_trunk_path_meets_parity_with_the_oracle():
         checked += 1
         assert abs(res.llk[c, 0] - want) <= llk_tol(want, row, m.JAFS, False), (c, split[c], params[c])
     assert checked >= 16
+
+
+def test_launch_shape_hint_does_not_change_results():
+    """A large batch that collapses into a few chains: the first evaluation packs several chains per
+    wavefront (the chain count is unknown to the host), the second one on the same context knows the
+    count from the first (pinned-memory hint) and runs one chain per wave with the trunk following it
+    in the same launch.  Same bits."""
+    from misti_amd.engine import Engine
+    inp = small_grid(True)
+    numT = len(inp.lambdas)
+    bands = [(0, 2, -1, 0.0, 0), (1, 1, 9, 0.15, -1)]
+    pulses = [(1, 6, 0.0, 1)]
+    splits = np.arange(10, numT - 4, dtype=float)
+    splits[::3] += 0.41
+    par = np.array([[0.02, 0.0], [0.2, 0.1], [0.6, 0.3]])
+    reps = 9000 // (len(splits) * len(par)) + 1
+    split = np.tile(np.repeat(splits, len(par)), reps)
+    params = np.tile(np.tile(par, (len(splits), 1)), (reps, 1))
+    assert len(split) > 8192
+    rows = [[3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]]
+    with Engine(inp.times, inp.lambdas, bands, pulses, n_param=2, cpfit=True, smooth=True) as e:
+        first = e.evaluate(split, params, rows, want_lc=True, want_pr=True)
+        second = e.evaluate(split, params, rows, want_lc=True, want_pr=True)
+    assert_identical(first, second)
+    n1 = len(splits) * len(par)
+    assert np.array_equal(first.llk[:n1], first.llk[n1:2 * n1], equal_nan=True)          # repeats of a candidate agree
+    assert (first.status == 0).mean() > 0.5
