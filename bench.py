@@ -79,7 +79,8 @@ def algorithmic_bytes(w, n_rep):
     """HBM bytes the algorithm needs per launch, per kernel.
 
     correction: one chain per distinct parameter vector, computed up to the largest split index of
-                its members: 8P in; per interval 16 B of rates + 48 B of pair state out;
+                its members: 8P in; per interval 16 B of rates + 48 B of pair state out (+ the trunk records,
+                1 056 B per chain and interval, when the trunk wave follows its chain in the same launch);
     spectrum:   per candidate split 8 + params 8P in, its share of the chain 16 B per two-population
                 interval + 48 B state, JAFS 56 + status 4 out (+ one trunk record of 1 056 B when chains are
                 shared; the trunk launch itself writes one record per chain and interval);
@@ -94,8 +95,13 @@ def algorithmic_bytes(w, n_rep):
             chains[row] = max(chains.get(row, 0), int(s))
     correct = sum(8 * P + 64 * L for L in chains.values())
     spectrum = int((8 + 8 * P + 16 * s_int + 48 + 60).sum())
-    if len(chains) * 8 <= n:                                  # TRUNK_MIN_SHARE (misti_consts.h)
-        spectrum += 1056 * n + sum(1056 * (L + 1) for L in chains.values())
+    if len(chains) * 8 <= n:                                  # TRUNK_MIN_SHARE (misti_consts.h): chains are shared, a trunk is built
+        trunk = sum(1056 * (L + 1) for L in chains.values())
+        spectrum += 1056 * n                                  # one trunk record per candidate
+        if len(chains) <= 256 or n <= 2048:                   # one chain per wave: the trunk wave follows its chain inside the chain launch
+            correct += trunk
+        else:
+            spectrum += trunk
     return {"correct": correct, "spectrum": spectrum, "llk": n * (60 + 8 * n_rep), "n_chains": len(chains)}
 
 

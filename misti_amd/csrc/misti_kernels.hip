@@ -1473,7 +1473,8 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                      int n_inline, const double* __restrict__ jsfs, const double* __restrict__ consts, double* __restrict__ llk_out) {
     extern __shared__ double lds[];
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    // everything per candidate is wave-uniform: keep it in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
     if (slot >= n_cand) return;
 #ifdef MISTI_STAMP2
@@ -1483,7 +1484,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
 #define KSTAMP(i)
 #endif
     KSTAMP(0)
-    const int64_t cand = order[slot];
+    const int64_t cand = (int64_t)__builtin_amdgcn_readfirstlane(order[slot]);
     const int lc_rows = m.numT + 1;
     double* xbuf = lds + (size_t)wave * (128 + 2 * lc_rows);
     double* lcb = xbuf + 128;
@@ -1493,7 +1494,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
     mod.cache();
     // ---- this candidate's share of its chain (+ its own tail interval after a fractional split)
-    const int64_t ch = chain_of(cb, cand);
+    const int64_t ch = (int64_t)__builtin_amdgcn_readfirstlane((int)chain_of(cb, cand));
     const int nfull = (G.ins >= 0) ? G.ins : G.split;          // intervals taken from the chain
     const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
     const double* tr_ch = cb.trace + ch * (int64_t)(m.numT + 1) * 6;
@@ -1657,21 +1658,6 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             // P(s) = V1 e^-s + V3 e^-3s + V6 e^-6s, s = int lc dt; occupation integral of
             // interval t is (1/lc_t) * int_{S_t}^{S_t+tau_t} P(s) ds (OnePopulation.py:153-178,
             // SolveDifEq :530-540 incl. the last, infinite interval).
-            double x0 = P8[0];
-            const double a3[3] = {1.0, 4.0, 1.0};
-            double X[3], V1[NS1], V3[NS1], V6[NS1];
-            for (int i = 0; i < 3; ++i) X[i] = P8[1 + i] + a3[i] * x0 / 3.0;
-            // b[j][i]: 3-lineage state i -> 2-lineage state 4+j (one-population generator / la)
-            const double bm[4][3] = {{2, 1, 0}, {0, 1, 2}, {1, 0, 1}, {0, 1, 0}};
-            V6[0] = x0; V3[0] = 0; V1[0] = 0;
-            for (int i = 0; i < 3; ++i) { V6[1 + i] = -a3[i] * x0 / 3.0; V3[1 + i] = X[i]; V1[1 + i] = 0; }
-            for (int j = 0; j < 4; ++j) {
-                double sx = 0, sa = 0;
-                for (int i = 0; i < 3; ++i) { sx += bm[j][i] * X[i]; sa += bm[j][i] * a3[i]; }
-                V6[4 + j] = sa * x0 / 15.0;
-                V3[4 + j] = -sx / 2.0;
-                V1[4 + j] = P8[4 + j] + sx / 2.0 - sa * x0 / 15.0;
-            }
             double G1 = 0, G3 = 0, G6 = 0;           // sum_t e^{-a S_t} (1 - e^{-a tau_t}) / (a lc_t)
             double carry = 0.0;
             const int last = G.numT - 1;
@@ -1693,6 +1679,22 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                 carry += bcast(inc, 63);
             }
             for (int o = 32; o > 0; o >>= 1) { G1 += __shfl_xor(G1, o, 64); G3 += __shfl_xor(G3, o, 64); G6 += __shfl_xor(G6, o, 64); }
+            // coefficient vectors of the three exponentials (after the sums: they are not live across the loop)
+            double x0 = P8[0];
+            const double a3[3] = {1.0, 4.0, 1.0};
+            double X[3], V1[NS1], V3[NS1], V6[NS1];
+            for (int i = 0; i < 3; ++i) X[i] = P8[1 + i] + a3[i] * x0 / 3.0;
+            // b[j][i]: 3-lineage state i -> 2-lineage state 4+j (one-population generator / la)
+            const double bm[4][3] = {{2, 1, 0}, {0, 1, 2}, {1, 0, 1}, {0, 1, 0}};
+            V6[0] = x0; V3[0] = 0; V1[0] = 0;
+            for (int i = 0; i < 3; ++i) { V6[1 + i] = -a3[i] * x0 / 3.0; V3[1 + i] = X[i]; V1[1 + i] = 0; }
+            for (int j = 0; j < 4; ++j) {
+                double sx = 0, sa = 0;
+                for (int i = 0; i < 3; ++i) { sx += bm[j][i] * X[i]; sa += bm[j][i] * a3[i]; }
+                V6[4 + j] = sa * x0 / 15.0;
+                V3[4 + j] = -sx / 2.0;
+                V1[4 + j] = P8[4 + j] + sx / 2.0 - sa * x0 / 15.0;
+            }
             // assemble: lane c < 7 holds class c
             double j1 = 0.0;
             const unsigned w1 = lane < 7 ? c_tab.jaf1_bits[lane] : 0u;
