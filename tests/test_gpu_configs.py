@@ -1,0 +1,88 @@
+"""BASELINE configs 3, 4 and 5 at FULL size through the C ABI, a sample of each against the oracle
+(config 2 is in test_gpu_grid.py).  Same contract: statuses equal; llk within 1e-9 (+ rounding
+floor) where the reference is determined; runaway-rate candidates only loosely; plus the properties
+each workload offers at full size."""
+import numpy as np
+import pytest
+
+from parity import llk_tol
+
+pytestmark = pytest.mark.gpu
+RUNAWAY = 5.0
+
+
+def evaluate(name):
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = getattr(workloads, name)(lambda *a: truth_spectrum(*a))
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        first = e.evaluate(w.split_time, w.params, w.jsfs)
+        again = e.evaluate(w.split_time, w.params, w.jsfs)          # second batch: launch shape from the first one's chain count
+    assert np.array_equal(first.llk, again.llk, equal_nan=True) and np.array_equal(first.status, again.status)
+    return w, first
+
+
+def against_oracle(w, res, n_sample, unfolded=False, min_regular=8):
+    from oracle.batch import oracle_batch
+    idx = np.linspace(0, w.n_cand - 1, n_sample).astype(int)
+    o_llk, o_st, _ = oracle_batch(w, idx, processes=8)
+    run = oracle_batch.last_runaway
+    assert (res.status[idx] == o_st).all()
+    n_reg = n_out = 0
+    for k, c in enumerate(idx):
+        if o_st[k] != 0:
+            assert np.isneginf(res.llk[c]).all()
+            continue
+        for r in range(0, res.llk.shape[1], max(1, res.llk.shape[1] // 5)):
+            err = abs(res.llk[c, r] - o_llk[k, r])
+            if run[k] < RUNAWAY:
+                n_reg += 1
+                if err > llk_tol(o_llk[k, r], w.jsfs[r], res.jafs[c], unfolded):
+                    n_out += 1                                            # a gtol stop/continue flip (see test_gpu_grid.py)
+                    assert err <= 1e-7 * abs(o_llk[k, r]), (c, r, res.llk[c, r], o_llk[k, r])
+            else:
+                assert err <= 1e-3 * abs(o_llk[k, r]), (c, r, res.llk[c, r], o_llk[k, r], run[k])
+    assert n_reg >= min_regular and n_out <= max(1, n_reg // 50)
+    return idx, o_st
+
+
+def test_config3_random_starts():
+    """16 384 random two-band starts, every start its own chain (no sharing): the packed kernel-1 path."""
+    w, res = evaluate("config3")
+    assert w.n_cand == 16384
+    against_oracle(w, res, 64, min_regular=40)
+    ok = res.status == 0
+    assert ok.mean() > 0.95
+    np.testing.assert_allclose(res.jafs[ok].sum(axis=1), 1.0, rtol=1e-12)
+    # the best start is close to the truth the data were generated from
+    best = np.argmax(np.where(ok, res.llk[:, 0], -np.inf))
+    assert res.llk[best, 0] > np.median(res.llk[ok, 0])
+
+
+def test_config4_bootstrap_scan():
+    """256 split values (a third fractional) x 1 000 bootstrap replicates, default fit, no migration: one
+    chain for the whole batch, the separate replicate kernel."""
+    w, res = evaluate("config4")
+    assert res.llk.shape == (256, w.jsfs.shape[0]) and w.jsfs.shape[0] >= 1000
+    against_oracle(w, res, 24, min_regular=24 * 5)
+    assert (res.status == 0).all()
+    # replicate epilogue: llk is linear in the replicate's counts given the spectrum -> row 0 (the sum of the
+    # chunks the others were resampled from) is reproduced from the spectrum by the host formula
+    from math import lgamma
+    d = w.jsfs[0][1:]
+    for c in (0, 100, 255):
+        J = res.jafs[c]
+        f = [d[0] + d[6], d[1] + d[5], d[2] + d[4], d[3]]
+        j = [J[0] + J[6], J[1] + J[5], J[2] + J[4], J[3]]
+        want = lgamma(sum(d) + 1) - sum(lgamma(v + 1) for v in f) + sum(a * np.log(b) for a, b in zip(f, j))
+        assert abs(res.llk[c, 0] - want) <= llk_tol(want, w.jsfs[0], J, False)
+
+
+def test_config5_pulse_grid_ancient_sample():
+    """32 x 64 x 32 split x rate x pulse grid with an ancient sample (65 536 candidates, 2 048 chains)."""
+    w, res = evaluate("config5")
+    assert w.n_cand == 65536
+    against_oracle(w, res, 64, min_regular=20)
+    ok = res.status == 0
+    assert ok.mean() > 0.9
+    np.testing.assert_allclose(res.jafs[ok].sum(axis=1), 1.0, rtol=1e-12)
