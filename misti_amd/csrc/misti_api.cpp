@@ -7,7 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <chrono>
 #include <complex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -73,6 +75,7 @@ struct misti_ctx {
     int64_t diag_n = 0;
     int32_t* hint_host = nullptr;       // pinned, device-visible: {chains, candidates} of the last batch (a launch-shape hint only)
     int32_t* hint_dev = nullptr;
+    int32_t batch_seq = 0;
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
@@ -202,19 +205,22 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.trunk_cap = (int64_t)ntr;
         cb.hint = c->hint_dev;
     }
-    // launch shape of kernel 1 from the number of chains the previous batch of this size had (the count lives on
-    // the device; the kernel drops it into pinned memory, no synchronisation).  A stale hint costs speed only.
-    int64_t est_chains = n_cand;
-    if (c->hint_host) {
-        const volatile int32_t* h = c->hint_host;
-        const int32_t h_chains = h[0], h_cand = h[1];
-        if (h_cand == (int32_t)n_cand && h_chains > 0 && h_chains <= n_cand) est_chains = h_chains;
-    }
+    // Launch shape of kernel 1 depends on the number of chains, which lives on the device: discover_kernel drops
+    // {chains, candidates, batch tag} into pinned memory.  A batch of the same size as the previous one on this
+    // context uses that one's count (no waiting; a stale value costs speed only); otherwise the host waits for
+    // this batch's own count - bounded, a few microseconds after the launch.
+    c->batch_seq += 1;
+    cb.seq = c->batch_seq;
+    int64_t est_chains = -1;
+    const volatile int32_t* hint = c->hint_host;
+    if (hint && hint[1] == (int32_t)n_cand && hint[0] > 0 && hint[0] <= n_cand) est_chains = hint[0];
     // chains per wavefront: packed (up to 8) when the batch is large - fewer instructions in total, which is what
     // counts when batches overlap - unless it is known to collapse into a few long chains (pure latency: one chain
     // per wave and the trunk following it)
-    const int cpw_chains = est_chains <= 256 ? 1 : misti::correct_cands_per_wave(n_cand);
-    const bool follow = misti::trunk_follows(cpw_chains, (int64_t)ntr);
+    auto shape = [&](int64_t est, int& cpw, bool& follow) {
+        cpw = (est >= 0 && est <= 256) ? 1 : misti::correct_cands_per_wave(n_cand);
+        follow = misti::trunk_follows(cpw, (int64_t)ntr);
+    };
     // a batch is five launches (six with more than LLK_INLINE_MAX replicates): prepare | discover | chains |
     // trunks + tails | candidates (+ replicate epilogue).  Few launches matter when many batches are in flight.
     int32_t* d_order = c->ws_order.as<int32_t>();
@@ -224,6 +230,14 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (int r = record_begin(c, 0, &a, &b)) return r;
     HIP_TRY(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream));
     HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->stream));
+    if (est_chains < 0 && hint && misti::correct_cands_per_wave(n_cand) > 1) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (hint[2] != cb.seq && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) std::this_thread::yield();
+        if (hint[2] == cb.seq && hint[1] == (int32_t)n_cand) est_chains = hint[0];
+    }
+    int cpw_chains = 1;
+    bool follow = false;
+    shape(est_chains, cpw_chains, follow);
     HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, c->stream));
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
@@ -337,7 +351,7 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         const int numT = model->numT;
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         if (hipHostMalloc((void**)&c->hint_host, 4 * sizeof(int32_t), hipHostMallocMapped) == hipSuccess) {
-            c->hint_host[0] = c->hint_host[1] = 0;
+            c->hint_host[0] = c->hint_host[1] = c->hint_host[2] = 0;
             if (hipHostGetDevicePointer((void**)&c->hint_dev, c->hint_host, 0) != hipSuccess) c->hint_dev = nullptr;
         } else { (void)hipGetLastError(); c->hint_host = nullptr; }
         c->stream = c->own_stream;

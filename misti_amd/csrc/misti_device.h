@@ -47,7 +47,7 @@ struct DevModel {
 // parameter vectors share a chain; chains are found by inserting every candidate into an open-addressing
 // table keyed by its parameters (discover_kernel): the first one in a slot owns the chain.
 struct ChainBufs {
-    int32_t* n_chains;      // [1]
+    int32_t* n_chains;      // [2]: chains; blocks of discover_kernel that have finished
     int32_t* table;         // [tsize] slot -> owner candidate + 1, 0 = empty
     int32_t* slot_chain;    // [tsize] slot -> chain
     int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
@@ -67,7 +67,8 @@ struct ChainBufs {
     double* trunk;          // [trunk_cap][numT][TRUNK_REC] per chain: 44-state vector + occupation integrals before interval t
     int32_t* trunk_ok;      // [trunk_cap] per chain: last valid record
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
-    int32_t* hint;          // host-pinned [2] or NULL: {chains, candidates} of this batch, read by the host before the NEXT one
+    int32_t* hint;          // host-pinned [3] or NULL: {chains, candidates, batch tag}, written by the last block of discover_kernel
+    int32_t seq;            // this batch's tag
 };
 
 __device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.of[cand]; }

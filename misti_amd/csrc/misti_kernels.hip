@@ -1111,7 +1111,6 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
         // 64/GROUP candidates, the chains occupy the first few): later kernels read it without the slot indirection
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
-        if (i == 0 && cb.hint) { cb.hint[0] = cb.n_chains[0]; cb.hint[1] = (int32_t)n_items; }   // to the host, for the next batch's launch shape
     }
     correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds);
 }
@@ -1440,7 +1439,6 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     if (threadIdx.x < 64) {
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;          // candidate -> chain (see correct_kernel)
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
-        if (i == 0 && cb.hint) { cb.hint[0] = cb.n_chains[0]; cb.hint[1] = (int32_t)n_items; }
         correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, lc_sh, flags);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (threadIdx.x == 0) flags[1] = 1;                                  // whatever way the chain ended
@@ -1745,31 +1743,46 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 __global__ __launch_bounds__(256)
 void discover_kernel(int64_t n, int P, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t h = 0x243f6a8885a308d3ull;
-    const double* a = params + i * P;
-    for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
-    uint32_t s = (uint32_t)(h >> 20) & cb.tmask;
-    for (;;) {
-        const int prev = atomicCAS(&cb.table[s], 0, (int)i + 1);
-        if (prev == 0) {
-            const int ch = atomicAdd(cb.n_chains, 1);
-            cb.chain_slot[ch] = (int32_t)s;
-            cb.rep[ch] = (int32_t)i;
-            cb.slot_chain[s] = ch;
-            break;
+    if (i < n) {
+        uint64_t h = 0x243f6a8885a308d3ull;
+        const double* a = params + i * P;
+        for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
+        uint32_t s = (uint32_t)(h >> 20) & cb.tmask;
+        for (;;) {
+            const int prev = atomicCAS(&cb.table[s], 0, (int)i + 1);
+            if (prev == 0) {
+                const int ch = atomicAdd(cb.n_chains, 1);
+                cb.chain_slot[ch] = (int32_t)s;
+                cb.rep[ch] = (int32_t)i;
+                cb.slot_chain[s] = ch;
+                break;
+            }
+            const double* b = params + (int64_t)(prev - 1) * P;
+            bool same = true;
+            for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) same = false;
+            if (same) break;
+            s = (s + 1) & cb.tmask;
         }
-        const double* b = params + (int64_t)(prev - 1) * P;
-        bool same = true;
-        for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) same = false;
-        if (same) break;
-        s = (s + 1) & cb.tmask;
+        cb.slot_of[i] = (int32_t)s;
+        const double st = split_time[i];
+        int need = 0;
+        if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
+        atomicMax(&cb.slot_len[s], need);
     }
-    cb.slot_of[i] = (int32_t)s;
-    const double st = split_time[i];
-    int need = 0;
-    if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
-    atomicMax(&cb.slot_len[s], need);
+    // the last block to finish tells the host how many chains there are: pinned memory, {chains, candidates, batch tag};
+    // the host uses it for the launch shape of kernel 1 (this batch if it cares to wait a few microseconds, else the next)
+    if (cb.hint) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(&cb.n_chains[1], 1) == (int)gridDim.x - 1) {
+                cb.hint[0] = atomicAdd(cb.n_chains, 0);
+                cb.hint[1] = (int32_t)n;
+                __threadfence_system();
+                cb.hint[2] = cb.seq;
+            }
+        }
+    }
 }
 
 uint32_t chain_table_size(int64_t n_cand) {
@@ -1800,7 +1813,7 @@ void prepare_kernel(int64_t n_cand, const double* __restrict__ split_time, int n
         auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
         for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
         __syncthreads();
-        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } cb.n_chains[0] = 0; }
+        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } cb.n_chains[0] = 0; cb.n_chains[1] = 0; }
         __syncthreads();
         for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
         if (gridDim.x > 1) return;
