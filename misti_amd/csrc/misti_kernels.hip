@@ -1,17 +1,26 @@
 // MI355X (gfx950) kernels of the MiSTI composite-likelihood engine.
 //
-// One wavefront (64 lanes) evaluates one candidate (split time, band rates, pulse
-// rates); the 44-state vector of the two-population chain lives one state per
-// lane; all per-interval rates are wave-uniform.  fp64 throughout, no MFMA (the
-// per-interval matrices are 3x3 / 44x44 with ~200 non-zeros).
+// A batch of candidates (split time, band rates, pulse rates) x bootstrap JSFS replicates is five
+// launches:
+//   prepare_kernel          dispatch order, chain-table reset, llh_const of the replicates
+//   discover_kernel         candidates with identical parameters share a CHAIN (hash table)
+//   correct_[follow_]kernel lambda-correction of the chains, a resumable state machine per chain;
+//                           with one chain per wave a second wave of the workgroup builds the
+//                           chain's TRUNK (44-state propagation shared by its candidates) behind it
+//   post_kernel             trunks that did not follow + tails (fractional splits)
+//   spectrum_kernel         one wavefront per candidate, the 44-state vector one state per lane:
+//                           own intervals after the trunk, collapse, one-population closed form,
+//                           normalisation, llk of up to 8 replicates  (llk_kernel beyond that)
+// fp64 throughout, no MFMA (the per-interval matrices are 3x3 / 44x44 with ~200 non-zeros).
 //
 // Reference path restated here (cites: /root/reference):
 //   JAFSLikelihood  MigrationInference.py:566-614     driver, status codes
-//   CorrectLambdas  MigrationInference.py:305-378     -> correct_two_pop(), post_split_rates()
-//   CorrectLambda   CorrectLambda.py:29-317           -> pair chain: pair_expv(), trf2_*()
-//   Smooth          MigrationInference.py:380-405     -> smooth_rates()
-//   JAFSpectrum     MigrationInference.py:467-540     -> spectrum_two_pop(), spectrum_one_pop()
+//   CorrectLambdas  MigrationInference.py:305-378     -> correct_body(), post-split rates in spectrum_kernel
+//   CorrectLambda   CorrectLambda.py:29-317           -> pair chain: pair_expv(), pair_batch(), next_step(), trf_bounded()
+//   Smooth          MigrationInference.py:380-405     -> smooth_rates(), run_mean()
+//   JAFSpectrum     MigrationInference.py:467-540     -> twopop_interval(), trunk_body()/trunk_follow(), spectrum_kernel
 //   TwoPopulations / OnePopulation                     -> tables (misti_tables.hpp) + closed form
+//   CoalescentRates MigrationInference.py:542-564     -> forward_kernel
 //
 // Numerical method (differs from the reference's dense Pade expm + inverse, same
 // mathematics): exp(M T) P0 and the occupation integral  int_0^T exp(M t) P0 dt
