@@ -848,10 +848,10 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 // MigrationInference.py:307-354; SolveLambdaSystem, CorrectLambda.py:266-317).
 //
 // The recursion over intervals does not depend on the split time except for where it stops:
-// candidates with the same parameter vector share one CHAIN (chain discovery below), computed
+// candidates with the same parameter vector share one CHAIN (discover_kernel), computed
 // once up to the largest split index of its members - in a split x rate sweep 64 chains instead of
 // 4 096.  A fractional split shortens the candidate's last two-population interval; that one
-// interval is a TAIL, run per candidate from the chain's state (second launch, TAIL = true).
+// interval is a TAIL, run per candidate from the chain's state (TAIL = true, in post_kernel).
 //
 // GROUP lanes per work item (6 carry the residual evaluations), no LDS beyond the staged grid.
 // Each item runs its own resumable state machine: one pass of the loop = one residual batch
