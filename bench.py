@@ -246,6 +246,7 @@ def main():
         "config": {"workload": w.name, "candidates_per_gpu": n, "replicates": R, "numT": w.numT, "streams": n_streams,
                    "parallelism": "candidates sharded per GPU, all_gather of llk (RCCL)" if world > 1 else "1 GPU"},
     }
+    out_spectra_per_s = world * n * a.steps / dt
     if rank == 0:
         # ---- roofline of the dominant kernel -----------------------------------------
         per = {k: (kms[k] / kn[k] if kn[k] else 0.0) for k in kms}          # ms per launch, HIP events on the launch stream
@@ -268,6 +269,16 @@ def main():
                            "note": "the path is neither HBM- nor MFMA-bound (SURVEY 8d): ~1 KB per candidate against ~1e5 dependent fp64 "
                                    "operations; the correction kernel is bound by the dependent-issue latency of its longest chain "
                                    "(serial trust-region iterations of the reference's solver), the spectrum kernel by fp64 VALU issue + LDS latency"}
+        # secondary figure SURVEY 8d asks for: the flop model of an UNSHARED evaluation (what the reference computes per
+        # candidate: ~16 sparse generator applications of 2 x 220 flop per two-population interval, ~5 kflop of 3x3
+        # exponentials per migrating interval, 0.1 kflop per one-population interval) x distinct spectra per second,
+        # against the fp64 vector peak.  Chain and trunk sharing EXECUTE far fewer flops than this model counts.
+        s_int = np.floor(w.split_time).astype(np.int64)
+        flop_per_spectrum = float(np.mean(s_int * (16 * 440 + 5000) + (w.numT - s_int) * 100))
+        eq_tflops = out_spectra_per_s * flop_per_spectrum / 1e12
+        out["roofline"]["fp64_equivalent"] = {"flop_per_spectrum_model": flop_per_spectrum, "equivalent": eq_tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                                              "unit": "TFLOP/s", "frac": eq_tflops / FP64_VALU_PEAK_TFLOPS,
+                                              "note": "reference-equivalent work per second (SURVEY 8d model of an unshared evaluation), not executed flops"}
         ok = status == 0
         out["status_fraction"] = {"ok": float(ok.mean()), "correction_failed": float((status == 2).mean()),
                                   "stiff": float((status == 6).mean()), "numeric": float((status == 5).mean())}
