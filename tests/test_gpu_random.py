@@ -55,7 +55,8 @@ def test_random_models_against_oracle():
             o_llk, o_jafs, o_st, run = oracle_eval(c["times"], c["lh"], c["bands"], c["pulses"], c["flags"], c["sd"], c["split"],
                                                    c["params"], [c["sfs"]])
         n_checked += 1
-        default_mig = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and any(True for _ in c["bands"])
+        # default fit with anything that mixes the pair states (band or pulse): reference-indeterminate
+        default_mig = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
         if o_st != 0 or r.status[0] != 0:
             # failure statuses must agree unless the reference is in its noise-driven regime
             if not (run >= 5.0 or default_mig):
