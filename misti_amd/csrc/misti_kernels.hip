@@ -1951,7 +1951,9 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 int64_t trunk_capacity(int64_t n_cand) {
     const char* e = getenv("MISTI_NO_TRUNK");              // read per call: tests toggle it
     const bool off = e && e[0] && e[0] != '0';
-    return off ? 0 : n_cand / TRUNK_MIN_SHARE;
+    if (off) return 0;
+    const int64_t cap = n_cand / TRUNK_MIN_SHARE;
+    return cap < TRUNK_MAX_CHAINS ? cap : TRUNK_MAX_CHAINS;   // beyond that many chains candidates walk their own intervals
 }
 
 // trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
