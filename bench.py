@@ -150,6 +150,7 @@ def main():
     d_all = torch.empty((world * n, R), dtype=torch.float64, device=dev) if use_dist else None
 
     comm_stream = torch.cuda.Stream() if use_dist else None
+    torch.cuda.synchronize()                          # inputs have landed before any lane (non-blocking streams) reads them
 
     class Lane:
         """One engine context + its output buffers on one HIP stream.

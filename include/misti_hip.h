@@ -159,6 +159,12 @@ int misti_eval_batch_dev(misti_ctx* ctx, int64_t n_cand,
 int misti_llk_dev(misti_ctx* ctx, int64_t n_cand, const double* d_jafs, const int32_t* d_status,
                   int64_t n_rep, const double* d_jsfs, double* d_llk);
 
+/* Bootstrap reduction on device buffers: per replicate r the candidate with the largest
+ * llk[c][r] (what test.bs/bs_conf_int.ipynb computes from the printed "llh =" lines before its
+ * Student-t interval).  -inf and NaN never win; ties go to the lowest index; best[r] = -1 when no
+ * candidate has a value.  d_best_llk may be NULL.  Asynchronous on the context's stream. */
+int misti_argmax_dev(misti_ctx* ctx, int64_t n_cand, int64_t n_rep, const double* d_llk, int32_t* d_best, double* d_best_llk);
+
 /* Diagnostic of the last batch evaluated on this context (either form): per candidate the
  * largest corrected rate x interval length before smoothing (NaN where the candidate has no
  * value, 0 with MISTI_TRUE_EPS).  From ~5 upwards the correction's residual is nearly flat in

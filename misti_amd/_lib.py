@@ -62,6 +62,7 @@ SYMBOLS = {
     "misti_llk_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "misti_forward_rates": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_forward_rates_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_argmax_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_last_diag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
     "misti_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_kernel_times": (C.c_int, [C.c_void_p, _PD, C.POINTER(C.c_int64), C.c_int]),
@@ -85,6 +86,15 @@ def load(build_if_missing=True):
         if not build_if_missing:
             raise MistiError(-3, "libmisti_hip.so is not built (%s); run misti_amd.build.build()" % path)
         _build.build()
+    # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; if this
+    # library is loaded first it binds the system ROCm runtime and a later `import torch` brings a second one into
+    # the process (observed: torch.cuda then intermittently reports "No HIP GPUs are available", and stream or
+    # memory handles cross runtimes).  Loaded after torch, the NEEDED libamdhip64.so.7 resolves to the runtime
+    # torch already mapped.  Without torch installed the system runtime is the only one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

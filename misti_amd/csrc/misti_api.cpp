@@ -445,6 +445,17 @@ int misti_llk_dev(misti_ctx* c, int64_t n_cand, const double* d_jafs, const int3
     return 0;
 }
 
+int misti_argmax_dev(misti_ctx* c, int64_t n_cand, int64_t n_rep, const double* d_llk, int32_t* d_best, double* d_best_llk) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
+    if (n_rep == 0) return 0;
+    if (!d_best || (n_cand > 0 && !d_llk)) return fail(MISTI_E_ARG, "llk / best is NULL");
+    if (n_cand > INT32_MAX) return fail(MISTI_E_LIMIT, "n_cand too large");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(misti::launch_argmax(n_cand, n_rep, d_llk, d_best, d_best_llk, c->stream));
+    return 0;
+}
+
 int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, int64_t n_rep, const double* jsfs,
                      double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");

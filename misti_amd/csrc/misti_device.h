@@ -93,6 +93,7 @@ hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* ord
                            int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
+hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream);
 hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
                       const double* consts, double* llk, int unfolded, hipStream_t stream);

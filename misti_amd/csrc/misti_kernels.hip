@@ -1870,6 +1870,29 @@ void llk_kernel(int64_t n_cand, const double* __restrict__ jafs, const int32_t* 
     }
 }
 
+// Bootstrap reduction (test.bs/bs_conf_int.ipynb: per replicate the split value with the largest
+// likelihood): thread = replicate, coalesced reads along the replicate axis; -inf / NaN are skipped,
+// ties go to the lowest candidate index (numpy.argmax), -1 when no candidate has a value.
+__global__ __launch_bounds__(256)
+void argmax_kernel(int64_t n_cand, int64_t n_rep, const double* __restrict__ llk, int32_t* __restrict__ best, double* __restrict__ best_llk) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rep) return;
+    double bv = -INFINITY;
+    int32_t bi = -1;
+    for (int64_t c = 0; c < n_cand; ++c) {
+        const double v = llk[c * n_rep + r];
+        if (v > bv) { bv = v; bi = (int32_t)c; }           // false for NaN and for -inf
+    }
+    best[r] = bi;
+    if (best_llk) best_llk[r] = bv;
+}
+
+hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream) {
+    if (n_rep <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_kernel, dim3((unsigned)((n_rep + 255) / 256)), dim3(256), 0, stream, n_cand, n_rep, llk, best, best_llk);
+    return hipGetLastError();
+}
+
 // ----------------------------------------------------------- launchers -------
 hipError_t upload_tables(const DevTables& t) {
     static double inv[INV_TABLE];

@@ -187,6 +187,11 @@ class Engine:
         v = lambda p: C.c_void_p(int(p)) if p else None
         _lib.check(self._lib.misti_llk_dev(self._ctx, int(n_cand), v(d_jafs), v(d_status), int(n_rep), v(d_jsfs), v(d_llk)))
 
+    def argmax_dev(self, n_cand, n_rep, d_llk, d_best, d_best_llk=0):
+        """``misti_argmax_dev``: per replicate the index of the best candidate (raw device addresses; asynchronous)."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        _lib.check(self._lib.misti_argmax_dev(self._ctx, int(n_cand), int(n_rep), v(d_llk), v(d_best), v(d_best_llk)))
+
     def sync(self):
         _lib.check(self._lib.misti_sync(self._ctx))
 

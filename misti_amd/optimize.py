@@ -152,3 +152,33 @@ def bootstrap_split_interval(llk, split_values, level=0.95):
     mean, sd = best.mean(), best.std(ddof=1) if n > 1 else 0.0
     half = stats.t.ppf(0.5 + level / 2, n - 1) * sd / np.sqrt(n) if n > 1 else 0.0
     return mean, (mean - half, mean + half), best
+
+
+def bootstrap_scan_dev(engine, split_values, jsfs_rows, params=None, level=0.95):
+    """A bootstrap scan that keeps the [n_split x n_rep] likelihood table on the device: one
+    ``misti_eval_batch_dev`` over the split values x all replicates, then ``misti_argmax_dev`` per
+    replicate; only the n_rep winning indices come back.  Returns what ``bootstrap_split_interval``
+    returns (mean, interval, per-replicate best split)."""
+    import torch
+    from scipy import stats
+    dev = torch.device("cuda", engine.device)
+    split = torch.as_tensor(np.asarray(split_values, dtype=float), device=dev)
+    rows = torch.as_tensor(np.asarray(jsfs_rows, dtype=float).reshape(-1, 8), device=dev).contiguous()
+    n, R = split.numel(), rows.shape[0]
+    par = None
+    if engine.n_param:
+        par = torch.as_tensor(np.asarray(params, dtype=float).reshape(n, engine.n_param), device=dev).contiguous()
+    llk = torch.empty((n, R), dtype=torch.float64, device=dev)
+    best = torch.empty(R, dtype=torch.int32, device=dev)
+    torch.cuda.current_stream(dev).synchronize()      # the engine's stream is non-blocking: inputs must have landed
+    engine.evaluate_dev(n, split.data_ptr(), par.data_ptr() if par is not None else 0, R, rows.data_ptr(), llk.data_ptr())
+    engine.argmax_dev(n, R, llk.data_ptr(), best.data_ptr())
+    engine.sync()
+    idx = best.cpu().numpy()
+    if (idx < 0).any():
+        raise ValueError("a replicate has no finite likelihood over the scan")
+    b = np.asarray(split_values, dtype=float)[idx]
+    m = b.size
+    mean, sd = b.mean(), b.std(ddof=1) if m > 1 else 0.0
+    half = stats.t.ppf(0.5 + level / 2, m - 1) * sd / np.sqrt(m) if m > 1 else 0.0
+    return mean, (mean - half, mean + half), b

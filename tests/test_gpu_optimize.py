@@ -61,3 +61,28 @@ def test_sharded_evaluation_single_rank(cfg3):
     full = eng.evaluate(w.split_time, w.params, w.jsfs)
     out = evaluate_sharded(lambda s, p, j: eng.evaluate(s, p, j).llk, w.split_time, w.params, w.jsfs)
     assert np.array_equal(out.numpy(), full.llk, equal_nan=True)
+
+
+def test_bootstrap_scan_on_device_matches_host_reduction():
+    """Config-4-like scan: the [n_split x n_rep] table stays on the device, misti_argmax_dev picks the best split per
+    replicate; same answer as the host reduction (numpy argmax) of the host-buffer evaluation."""
+    import torch
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    from misti_amd.optimize import bootstrap_scan_dev, bootstrap_split_interval
+    w = workloads.config4(lambda *a: truth_spectrum(*a))
+    rows = w.jsfs[:200]
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        host = e.evaluate(w.split_time, w.params, rows)
+        mean_h, ci_h, best_h = bootstrap_split_interval(host.llk, w.split_time)
+        mean_d, ci_d, best_d = bootstrap_scan_dev(e, w.split_time, rows)
+        # the raw reduction incl. candidates without a value and a replicate without any
+        llk = torch.tensor([[1.0, -np.inf, np.nan], [3.0, -np.inf, np.nan], [3.0, -np.inf, -np.inf], [np.nan, -np.inf, np.nan]],
+                           dtype=torch.float64, device="cuda")
+        best = torch.empty(3, dtype=torch.int32, device="cuda")
+        val = torch.empty(3, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()                       # the engine issues on its own non-blocking stream
+        e.argmax_dev(4, 3, llk.data_ptr(), best.data_ptr(), val.data_ptr())
+        e.sync()
+    assert np.array_equal(best_h, best_d) and mean_h == mean_d and ci_h == ci_d
+    assert best.cpu().tolist() == [1, -1, -1] and val.cpu().tolist()[0] == 3.0
