@@ -6,14 +6,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path (chain discovery, lambda-correction kernel, spectrum
-kernel, replicate/llk kernel) over one batch: the 4 096-point grid of config 2 (64 split
-indices x 64 rates of one band `-mi 1 4 {st} {r} 1`, `--cpfit`, numT = 128) with
-inputs already resident in HBM.  The K timed steps are issued round-robin on `--streams`
-HIP streams (default 16) so that independent batches overlap; the strictly serial rate
-and the per-kernel durations are measured in the same run and reported beside it.  With N > 1 every rank evaluates its own 4 096-point
-grid (weak scaling; the grids differ by a per-rank shift of the rate axis) and the
-log-likelihoods are all-gathered over RCCL each step.  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path (prepare, chain discovery, lambda-correction of the chains
+with their trunks following, tails, spectrum kernel with the replicate epilogue) over one
+batch: the 4 096-point grid of config 2 (64 split indices x 64 rates of one band
+`-mi 1 4 {st} {r} 1`, `--cpfit`, numT = 128) with inputs already resident in HBM.  The K
+timed steps are issued round-robin on `--streams` lanes (one engine context + its own HIP
+stream each; default 20, 14 per rank with several ranks) so that independent batches
+overlap; the strictly serial rate and the per-kernel durations are measured in the same
+run and reported beside it.  With N > 1 every rank evaluates its own 4 096-point grid (weak
+scaling; the grids differ by a per-rank shift of the rate axis) and the log-likelihoods are
+all-gathered over RCCL each step.  Rank 0 prints ONE JSON line on stdout (everything else
+goes to stderr).
 """
 from __future__ import annotations
 
