@@ -36,8 +36,9 @@ sys.path.insert(0, ROOT)
 # one-to-one onto hardware queues up to 24 queues per process; one queue more and the driver time-slices
 # them (throughput collapses 2x).  22 lanes is the single-process peak; defaults leave room for the null
 # stream and, with several ranks, for RCCL's and torch's own streams.
-# (single rank with RCCL initialised: 18 lanes fine, 20 collapse -> 14 with several ranks, 4 queues spare)
-DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 14
+# (single rank with RCCL initialised and the per-batch all_gather: best at 18-19 lanes, slowly worse beyond -> 16
+# with several ranks)
+DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 16
 HW_QUEUES = 24
 HW_QUEUE_SLACK = 4
 
@@ -152,7 +153,6 @@ def main():
     d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
     d_all = torch.empty((world * n, R), dtype=torch.float64, device=dev) if use_dist else None
 
-    comm_stream = torch.cuda.Stream() if use_dist else None
     torch.cuda.synchronize()                          # inputs have landed before any lane (non-blocking streams) reads them
 
     class Lane:
@@ -168,31 +168,20 @@ def main():
                 self.stream = stream
             else:
                 self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
-            # two result buffers per lane: the gather of step i reads one while step i+1 fills the other
-            self.llk_bufs = [torch.empty((n, R), dtype=torch.float64, device=dev) for _ in range(2 if use_dist else 1)]
-            self.llk = self.llk_bufs[0]
+            self.llk = torch.empty((n, R), dtype=torch.float64, device=dev)
             self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
             self.status = torch.empty(n, dtype=torch.int32, device=dev)
-            self.gathered = [None, None]
-            self.turn = 0
 
         def step(self):
-            k = self.turn
-            self.turn = (k + 1) % len(self.llk_bufs)
-            self.llk = self.llk_bufs[k]
-            if self.gathered[k] is not None:                   # the gather issued two steps ago on this lane still reads this buffer
-                self.stream.wait_event(self.gathered[k])
             self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
                                   self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
             if use_dist:
-                # one communicator: gathers are serialised on a dedicated stream, in issue order on every rank
-                done = torch.cuda.Event()
-                done.record(self.stream)
-                comm_stream.wait_event(done)
-                with torch.cuda.stream(comm_stream):
+                # the batch's collective, issued from the lane's own stream: c10d orders it after the batch (event
+                # on this stream), runs it on its communicator stream in host issue order - the same on every rank -
+                # and makes this stream wait for it, so the next batch of the lane cannot overwrite llk early.
+                # (A dedicated communication stream + events per step cost a hardware queue and 15 % of the rate.)
+                with torch.cuda.stream(self.stream):
                     dist.all_gather_into_tensor(d_all, self.llk)
-                    self.gathered[k] = torch.cuda.Event()
-                    self.gathered[k].record(comm_stream)
 
     def fence():
         if use_dist:
