@@ -1,0 +1,105 @@
+"""Maximum sizes of the C ABI (include/misti_hip.h): the largest grid (numT = 255), the largest model structure
+(8 bands, 8 pulses, 16 parameters), a batch of 2^18 candidates, and the documented rejections beyond them."""
+import io
+
+import numpy as np
+import pytest
+
+from parity import llk_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def grid(n1, n2):
+    from misti_amd import synth, io as mio
+    return mio.merge_psmc(mio.read_psmc_file(io.StringIO(synth.psmc_text(n1, 1, synth.THETA_1))),
+                          mio.read_psmc_file(io.StringIO(synth.psmc_text(n2, 2, synth.THETA_2))))
+
+
+def test_largest_grid_against_oracle():
+    """numT = 255 (MISTI_MAX_NUMT): two PSMC files of 128 intervals each; a split scan sharing one chain."""
+    from misti_amd.engine import Engine
+    from oracle.misti_oracle import OracleModel
+    inp = grid(128, 128)
+    assert len(inp.lambdas) == 255
+    row = [3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]
+    splits = np.array([10.0, 77.0, 130.5, 200.0, 240.0, 253.0])
+    with Engine(inp.times, inp.lambdas, [(0, 3, -1, 0.0, 0)], [], n_param=1, cpfit=True, smooth=True) as e:
+        res = e.evaluate(np.repeat(splits, 2), np.tile([0.05, 0.2], len(splits)).reshape(-1, 1), [row], want_lc=True)
+    checked = 0
+    for c, (s, p) in enumerate(zip(np.repeat(splits, 2), np.tile([0.05, 0.2], len(splits)))):
+        m = OracleModel(list(inp.times), [list(x) for x in inp.lambdas], row, float(s), [[1, 3, int(np.ceil(s)), float(p), 1]], [],
+                        cpfit=True, smooth=True)
+        want = m.jafs_likelihood([float(p)])
+        if not np.isfinite(want):
+            assert res.status[c] != 0
+            continue
+        assert res.status[c] == 0
+        if res.runaway[c] < 5.0:
+            checked += 1
+            assert abs(res.llk[c, 0] - want) <= llk_tol(want, row, m.JAFS, False), (s, p)
+        else:
+            assert abs(res.llk[c, 0] - want) <= 1e-3 * abs(want)
+    assert checked >= 4
+    # one interval more is refused when the context is created
+    from misti_amd._lib import MistiError
+    big = grid(129, 128)
+    assert len(big.lambdas) == 256
+    with pytest.raises(MistiError):
+        Engine(big.times, big.lambdas)
+
+
+def test_largest_model_structure():
+    """8 bands + 8 pulses with 16 optimised parameters (the limits of misti_model_t); one more of each is refused."""
+    from misti_amd.engine import Engine
+    from misti_amd._lib import MistiError
+    from oracle.misti_oracle import OracleModel
+    inp = grid(16, 17)
+    numT = len(inp.lambdas)
+    bands = [(k % 2, 2 * (k // 2), 2 * (k // 2) + 2, 0.0, k) for k in range(8)]          # both directions over intervals 0..8
+    pulses = [((k + 1) % 2, 9 + k, 0.0, 8 + k) for k in range(8)]                      # one pulse per interval 9..16
+    par = [0.05 + 0.01 * k for k in range(8)] + [0.02 + 0.01 * k for k in range(8)]
+    row = [3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]
+    split = 20.0
+    mis = [[b[0] + 1, b[1], b[2], par[b[4]], 1] for b in bands]
+    pus = [[p[0] + 1, p[1], par[p[3]], 1] for p in pulses]
+    for kw_e, kw_o in ((dict(true_eps=True), dict(trueEPS=True)), (dict(cpfit=True, smooth=True), dict(cpfit=True, smooth=True))):
+        with Engine(inp.times, inp.lambdas, bands, pulses, n_param=16, **kw_e) as e:
+            res = e.evaluate([split], [par], [row])
+        m = OracleModel(list(inp.times), [list(x) for x in inp.lambdas], row, split, mis, pus, **kw_o)
+        want = m.jafs_likelihood(par)
+        if not np.isfinite(want):                       # random rates + 8 pulses: the correction fails in the reference as well
+            assert res.status[0] == m.status if hasattr(m, "status") else res.status[0] != 0
+            continue
+        assert res.status[0] == 0
+        assert abs(res.llk[0, 0] - want) <= llk_tol(want, row, m.JAFS, False) or res.runaway[0] >= 5.0
+        if "true_eps" in kw_e:
+            assert abs(res.llk[0, 0] - want) <= llk_tol(want, row, m.JAFS, False)
+    with pytest.raises(MistiError):
+        Engine(inp.times, inp.lambdas, bands + [(0, 18, 19, 0.1, -1)], pulses, n_param=16, cpfit=True)
+    with pytest.raises(MistiError):
+        Engine(inp.times, inp.lambdas, bands, pulses + [(0, 18, 0.1, -1)], n_param=16, cpfit=True)
+    with pytest.raises(MistiError):
+        Engine(inp.times, inp.lambdas, bands, pulses, n_param=17, cpfit=True)
+
+
+def test_quarter_million_candidates():
+    """2^18 candidates in one call (512 splits-with-repeats x 512 rates): every repeat of a candidate gives the same bits,
+    and a sample agrees with a small batch of the same candidates."""
+    from misti_amd.engine import Engine
+    inp = grid(16, 17)
+    numT = len(inp.lambdas)
+    splits = np.tile(np.arange(8, 24, dtype=float), 32)             # 512 split values, 16 distinct
+    rates = np.logspace(-3, -0.5, 512)
+    st, rr = np.meshgrid(splits, rates, indexing="ij")
+    split, params = st.ravel(), rr.ravel()[:, None]
+    row = [3e7, 9000, 2500, 10000, 6000, 4000, 2600, 4100]
+    with Engine(inp.times, inp.lambdas, [(0, 2, -1, 0.0, 0)], [], n_param=1, cpfit=True, smooth=True) as e:
+        big = e.evaluate(split, params, [row])
+        idx = np.arange(0, len(split), 4099)
+        small = e.evaluate(split[idx], params[idx], [row])
+    assert len(split) == 1 << 18
+    assert np.array_equal(big.llk[idx], small.llk, equal_nan=True) and np.array_equal(big.status[idx], small.status)
+    a = big.llk.reshape(32, 16, 512)
+    assert all(np.array_equal(a[0], a[k], equal_nan=True) for k in range(1, 32))
+    assert (big.status == 0).mean() > 0.5
