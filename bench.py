@@ -212,6 +212,11 @@ def main():
 
     n_streams = max(1, a.streams)
     main_lanes = [Lane() for i in range(n_streams)]
+    # context initialisation, not measurement: the first batch of a context allocates its workspaces (hipMalloc) and
+    # learns its launch shape; every lane does that once here so that a short run (K < lanes x a few) times steady state
+    for lane in main_lanes:
+        lane.step()
+    fence()
     dt = timed(main_lanes, timing=False)
     issue_main = host_issue[0]
     # strictly serial pass on one stream: per-kernel durations (HIP events on the launch stream) and the serial rate
