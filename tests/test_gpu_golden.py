@@ -57,3 +57,15 @@ def test_small(case):
 @pytest.mark.parametrize("case", SYNTH, ids=[c["name"] for c in SYNTH])
 def test_synthetic(case):
     check(case)
+
+
+def test_c_example(tmp_path):
+    """examples/anchor_a2.c: the C ABI from plain C, no Python in the process - SURVEY anchor A2."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = dict(l.split(" = ") for l in r.stdout.splitlines() if " = " in l)
+    assert int(out["status"]) == 0
+    assert abs(float(out["llh"]) - (-183.1995404505269)) <= 1e-9 * 183.2

@@ -125,3 +125,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
                 text = open(os.path.join(base, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "anchor_a2")
+    libdir = os.path.dirname(_lib.lib_path())
+    _lib.load()                                              # builds the library if it is missing
+    cmd = ["gcc", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", "anchor_a2.c"), "-L", libdir, "-lmisti_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+def test_header_is_plain_c_and_the_example_links(tmp_path):
+    """include/misti_hip.h compiles as C99 (no C++/torch types at the boundary) and a C program links against the .so;
+    without a HIP device it reports the fact and exits 2 (no CPU path)."""
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    if _lib.load().misti_device_count() > 0:
+        pytest.skip("a GPU is present: the run itself is tests/test_gpu_golden.py::test_c_example")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
