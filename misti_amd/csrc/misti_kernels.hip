@@ -1910,7 +1910,8 @@ size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 
 // wave 4.5 ms, 4 per wave 4.9 ms, 2 per wave 5.4 ms; packing also executes fewer instructions in total,
 // which is what counts when batches overlap.)
 int correct_cands_per_wave(int64_t n_items) {
-    static const int forced = [] { const char* e = getenv("MISTI_CANDS_PER_WAVE"); return e ? atoi(e) : 0; }();
+    const char* e = getenv("MISTI_CANDS_PER_WAVE");       // diagnostic override, read per call: tests toggle it
+    const int forced = e ? atoi(e) : 0;
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
     int cpw = 1;
     while (cpw < 8 && n_items / cpw > 2048) cpw *= 2;

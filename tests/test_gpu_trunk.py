@@ -137,3 +137,29 @@ def test_launch_shape_hint_does_not_change_results():
     n1 = len(splits) * len(par)
     assert np.array_equal(first.llk[:n1], first.llk[n1:2 * n1], equal_nan=True)          # repeats of a candidate agree
     assert (first.status == 0).mean() > 0.5
+
+
+def test_chains_per_wave_do_not_change_results():
+    """Kernel 1 packs 1, 2, 4 or 8 chains into a wavefront depending on the batch; a chain's arithmetic is the same in
+    every packing (group-uniform series lengths, group-local broadcasts): same bits for all four, on unshared random
+    starts (config 3 shape) and on a shared grid with pulses and an ancient sample (config 5 shape, a sample)."""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w3 = workloads.config3(lambda *a: truth_spectrum(*a), n_start=1500)
+    w5 = workloads.config5(lambda *a: truth_spectrum(*a))
+    idx = np.arange(0, w5.n_cand, 23)
+    out = {}
+    for cpw in ("1", "2", "4", "8"):
+        os.environ["MISTI_CANDS_PER_WAVE"] = cpw
+        try:
+            with Engine(w3.times, w3.lh, **w3.engine_kwargs()) as e:
+                a = e.evaluate(w3.split_time, w3.params, w3.jsfs, want_lc=True, want_pr=True)
+            with Engine(w5.times, w5.lh, **w5.engine_kwargs()) as e:
+                b = e.evaluate(w5.split_time[idx], w5.params[idx], w5.jsfs, want_lc=True, want_pr=True)
+        finally:
+            os.environ.pop("MISTI_CANDS_PER_WAVE", None)
+        out[cpw] = (a, b)
+    for cpw in ("2", "4", "8"):
+        assert_identical(out["1"][0], out[cpw][0])
+        assert_identical(out["1"][1], out[cpw][1])
+    assert (out["1"][0].status == 0).mean() > 0.9
