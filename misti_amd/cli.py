@@ -109,6 +109,13 @@ def grid_mode(a, inp, rows):
     best = np.unravel_index(np.argmax(np.where(np.isfinite(res.llk), res.llk, -np.inf)), res.llk.shape)
     print("\nbest: splitT =", split[best[0]], "params =", None if params is None else list(params[best[0]]),
           "replicate =", best[1], "llh =", res.llk[best])
+    if a.all_bs and len(splits) > 1 and data.shape[0] > 1:
+        # the bootstrap confidence interval of test.bs/bs_conf_int.ipynb: per replicate the split of the best candidate,
+        # then a Student-t interval of those maxima (row 0 of a -bs file is the sum of the chunks, as there)
+        from .optimize import bootstrap_split_interval
+        mean, (lo, hi), best_split = bootstrap_split_interval(res.llk, split)
+        print("bootstrap: best splitT per replicate mean = %.6g, 95%% interval = [%.6g, %.6g] over %d replicates"
+              % (mean, lo, hi, data.shape[0]))
     print("Evaluated %d candidates x %d replicates in %.3f s (%.0f llk evals/s); %.1f%% without a value"
           % (len(split), data.shape[0], dt, res.llk.size / dt, 100 * res.fraction_failed))
     return 0

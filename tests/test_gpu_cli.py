@@ -74,3 +74,7 @@ def test_optimised_band_and_grid(tmp_path):
     assert rc == 0
     assert len(re.findall(r"^bs_id = ", text, flags=re.M)) == 5 * 4 * 5
     assert "best: splitT =" in text
+    m = re.search(r"bootstrap: best splitT per replicate mean = (\S+), 95% interval = \[(\S+), (\S+)\] over 5 replicates", text)
+    assert m, text[-800:]
+    mean, lo, hi = (float(v) for v in m.groups())
+    assert 18 <= lo <= mean <= hi <= 22
