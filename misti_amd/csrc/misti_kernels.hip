@@ -80,7 +80,7 @@ __device__ __forceinline__ double gbcast(double v, int j) {
         int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
         return __hiloint2double(hi, lo);
     }
-    return __shfl(v, (lane_id() & ~(GROUP - 1)) + j, 64);
+    return __shfl(v, (lane_id() - lane_id() % GROUP) + j, 64);     // GROUP = 6: ten items per wave, lanes 60-63 idle
 }
 
 __device__ __forceinline__ void lds_fence() {
@@ -853,7 +853,7 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 // 4 096.  A fractional split shortens the candidate's last two-population interval; that one
 // interval is a TAIL, run per candidate from the chain's state (TAIL = true, in post_kernel).
 //
-// GROUP lanes per work item (6 carry the residual evaluations), no LDS beyond the staged grid.
+// GROUP lanes per work item (64, 32, 16, 8 or 6; six carry the residual evaluations), no LDS beyond the staged grid.
 // Each item runs its own resumable state machine: one pass of the loop = one residual batch
 // (trial point + its forward-difference points) + the trust-region bookkeeping of
 // trf_no_bounds (trf.py:401-560), so the items of a wavefront never wait for each other
@@ -863,9 +863,10 @@ __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
                   int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr) {
     const int lane = lane_id();
-    const int sub = lane & (GROUP - 1);
-    const int64_t slot = (block * (64 / GROUP)) + (lane / GROUP);
+    const int sub = lane % GROUP;
     const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
+    // GROUP = 6 packs ten items into a wave; its last four lanes belong to no item
+    const int64_t slot = (lane / GROUP < 64 / GROUP) ? (block * (64 / GROUP)) + (lane / GROUP) : n_live;
     if (TAIL) {
         // a wave none of whose items has a fractional split has nothing to do: leave before staging
         bool mine = false;
@@ -1906,16 +1907,18 @@ hipError_t upload_tables(const DevTables& t) {
 size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
 
 // Work items per wavefront.  Kernel 1 holds two wavefronts per SIMD (208 VGPRs), 2 048 on the chip: as few
-// items per wave as keep the launch within one resident round, up to 8.  (Measured, 16 384 chains: 8 per
-// wave 4.5 ms, 4 per wave 4.9 ms, 2 per wave 5.4 ms; packing also executes fewer instructions in total,
-// which is what counts when batches overlap.)
+// items per wave as keep the launch within one resident round - 1, 2, 4 - and beyond that ten (six lanes per
+// item, none spare).  (Measured, 16 384 chains: 10 per wave 4.5 ms, 8 per wave 4.5 ms, 4 per wave 4.9 ms,
+// 2 per wave 5.4 ms; packing also executes fewer instructions in total, which is what counts when batches
+// overlap: 6.8 against 6.2 and 4.8 million evaluations/s for 10, 8 and 4 per wave.)  A chain's bits do not
+// depend on the packing (tests/test_gpu_trunk.py).
 int correct_cands_per_wave(int64_t n_items) {
     const char* e = getenv("MISTI_CANDS_PER_WAVE");       // diagnostic override, read per call: tests toggle it
     const int forced = e ? atoi(e) : 0;
-    if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 10) return forced;
     int cpw = 1;
     while (cpw < 8 && n_items / cpw > 2048) cpw *= 2;
-    return cpw;
+    return cpw == 8 ? 10 : cpw;
 }
 
 static size_t correct_lds_bytes(int numT) { return (size_t)(3 * numT - 1) * sizeof(double); }
@@ -1948,6 +1951,7 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 
 #define MISTI_DISPATCH_GROUP(FN, ...)                                                                   \
     switch (cpw) {                                                                                       \
+        case 10: cp ? FN<true, 6>(__VA_ARGS__) : FN<false, 6>(__VA_ARGS__); break;                       \
         case 8: cp ? FN<true, 8>(__VA_ARGS__) : FN<false, 8>(__VA_ARGS__); break;                        \
         case 4: cp ? FN<true, 16>(__VA_ARGS__) : FN<false, 16>(__VA_ARGS__); break;                      \
         case 2: cp ? FN<true, 32>(__VA_ARGS__) : FN<false, 32>(__VA_ARGS__); break;                      \

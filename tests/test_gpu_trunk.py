@@ -149,7 +149,7 @@ def test_chains_per_wave_do_not_change_results():
     w5 = workloads.config5(lambda *a: truth_spectrum(*a))
     idx = np.arange(0, w5.n_cand, 23)
     out = {}
-    for cpw in ("1", "2", "4", "8"):
+    for cpw in ("1", "2", "4", "8", "10"):
         os.environ["MISTI_CANDS_PER_WAVE"] = cpw
         try:
             with Engine(w3.times, w3.lh, **w3.engine_kwargs()) as e:
@@ -159,7 +159,7 @@ def test_chains_per_wave_do_not_change_results():
         finally:
             os.environ.pop("MISTI_CANDS_PER_WAVE", None)
         out[cpw] = (a, b)
-    for cpw in ("2", "4", "8"):
+    for cpw in ("2", "4", "8", "10"):
         assert_identical(out["1"][0], out[cpw][0])
         assert_identical(out["1"][1], out[cpw][1])
     assert (out["1"][0].status == 0).mean() > 0.9
