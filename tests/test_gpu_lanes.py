@@ -25,3 +25,14 @@ def test_pool_matches_sequential_evaluation():
             r = e.evaluate(split, params, rows)
             assert np.array_equal(r.status, status)
             assert np.array_equal(r.llk, llk, equal_nan=True) and np.array_equal(r.jafs, jafs, equal_nan=True)
+
+
+def test_python_api_example_recovers_the_true_split():
+    """examples/bootstrap_scan.py end to end in its own process: device-resident bootstrap scan + lane pool."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "bootstrap_scan.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "best split 64.00" in r.stdout and "40 scans on 8 lanes" in r.stdout
