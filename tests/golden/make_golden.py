@@ -129,6 +129,12 @@ def anchors():
     c.append(case("B12", T, L, S, 1, cpfit=True, smooth=True))
     c.append(case("B13", T, L, S, 0, cpfit=True, smooth=True))
     c.append(case("B14", T, L, S, 5, two, params=[30.0, 0.1], smooth=True, cpfit=True))
+    # mixture threshold (-mth) that does not fire / fires late: the guard of SolveLambdaSystem (CorrectLambda.py:267-272)
+    c.append(case("B15", T, L, S, 5, two, params=[0.3, 0.1], smooth=True, cpfit=True, mixtureTH=0.05))
+    c.append(case("B16", T, L, S, 5, two, params=[2.0, 1.5], smooth=True, cpfit=True, mixtureTH=0.3))
+    c.append(case("B17", T, L, S, 5, two, params=[0.3, 0.1], smooth=True, mixtureTH=0.05))
+    c.append(case("B18", T, L, S, 5, two, params=[0.3, 0.1], smooth=True, cpfit=True, mixtureTH=1.5))       # fires: correction failed
+    c.append(case("B19", T, L, S, 5, two, params=[3.0, 3.0], smooth=True, cpfit=True, mixtureTH=0.5))       # fires after the pairs have mixed
     return c
 
 
