@@ -60,3 +60,58 @@ def test_batching_and_sharing_never_change_a_result():
         n_cand += n
         n_ok += int((base.status == 0).sum())
     assert n_models == 160 and n_cand > 1500 and n_ok > n_cand // 2
+
+
+def test_time_rescaling_and_population_swap_on_random_models():
+    """Two symmetries of the model that no implementation detail shares between the two evaluations:
+    rescaling time by a power of two (interval lengths x a, every rate / a) leaves the normalised spectrum unchanged;
+    swapping the populations permutes its classes (0100<->0001, 1100<->0011, 1101<->0111).  Random models with all
+    flag combinations, bands, pulses, fractional splits (sample date 0: an ancient second genome breaks the swap)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import random_campaign as rc
+    from misti_amd.engine import Engine
+    rng = np.random.default_rng(24680)
+    perm = [2, 5, 0, 3, 6, 1, 4]
+    n_scale = n_swap = n_models = 0
+    worst_scale = worst_swap = 0.0
+    while n_models < 120:
+        c = rc.random_batch(rng)
+        if c["sd"] != 0:
+            continue
+        n_models += 1
+        noisy_fit = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
+        kw = dict(n_param=c["P"], sample_date=0, **c["flags"])
+        with Engine(c["times"], c["lh"], c["bands"], c["pulses"], **kw) as e:
+            base = e.evaluate(c["split"], c["params"], [c["sfs"]])
+        a = 4.0
+        par_scaled = None
+        if c["P"]:
+            par_scaled = c["params"].copy()
+            for (pop, s, en, v, par) in c["bands"]:
+                if par >= 0:
+                    par_scaled[:, par] /= a                      # rates scale, pulse fractions do not
+        bands_scaled = [(pop, s, en, v / a, par) for (pop, s, en, v, par) in c["bands"]]
+        with Engine(np.array(c["times"]) * a, np.array(c["lh"]) / a, bands_scaled, c["pulses"], **kw) as e:
+            scaled = e.evaluate(c["split"], par_scaled, [c["sfs"]])
+        bands_sw = [(1 - pop, s, en, v, par) for (pop, s, en, v, par) in c["bands"]]
+        pulses_sw = [(1 - pop, t, v, par) for (pop, t, v, par) in c["pulses"]]
+        with Engine(c["times"], np.array(c["lh"])[:, ::-1].copy(), bands_sw, pulses_sw, **kw) as e:
+            swapped = e.evaluate(c["split"], c["params"], [c["sfs"]])
+        for k in range(len(c["split"])):
+            determined = (not noisy_fit) and base.status[k] == 0 and base.runaway[k] < 5.0
+            if not determined:
+                continue
+            assert scaled.status[k] == 0 and swapped.status[k] == 0, (c, k)
+            d2 = np.max(np.abs(swapped.jafs[k][perm] / base.jafs[k] - 1))
+            worst_swap = max(worst_swap, d2)
+            n_swap += 1
+            assert d2 < 1e-9, (c, k, d2)
+            if c["flags"]["cpfit"]:
+                # only --cpfit is scale-free: the default fit stops SciPy's solver on an ABSOLUTE gradient tolerance of a
+                # residual in time units (expected coalescence time), also in the post-split refit that runs with trueEPS
+                d1 = np.max(np.abs(scaled.jafs[k] / base.jafs[k] - 1))
+                worst_scale = max(worst_scale, d1)
+                n_scale += 1
+                assert d1 < 1e-9, (c, k, d1)
+    print("time rescaling worst %.3g over %d candidates, population swap worst %.3g over %d" % (worst_scale, n_scale, worst_swap, n_swap))
+    assert n_scale > 300 and n_swap > 400
