@@ -38,7 +38,7 @@ int main(void) {
     const double split = 5.0;
     double llk = 0.0, jafs[7];
     int32_t status = -1;
-    if (misti_eval_batch(ctx, 1, &split, NULL, 1, jsfs, &llk, jafs, NULL, NULL, &status) != 0) {
+    if (misti_eval_batch(ctx, 1, &split, NULL, NULL, 1, jsfs, &llk, jafs, NULL, NULL, &status) != 0) {
         fprintf(stderr, "misti_eval_batch: %s\n", misti_last_error());
         misti_destroy(ctx);
         return 1;

@@ -21,7 +21,10 @@
  *     calls exit() or lets a C++ exception cross the ABI; misti_last_error()
  *     gives the message of the last failure on the calling thread;
  *   - a context is used by one host thread at a time; work is issued on one HIP
- *     stream per context (replaceable with misti_set_stream);
+ *     stream per context (replaceable with misti_set_stream).  Every batch of a
+ *     context uses the same device workspaces, so batches of one context are
+ *     ordered: misti_set_stream makes the new stream wait for everything already
+ *     issued on the old one.  Use several contexts for concurrent batches;
  *   - there is NO CPU fallback: without a HIP device misti_create fails.
  */
 #ifndef MISTI_HIP_H
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MISTI_ABI_VERSION 1
+#define MISTI_ABI_VERSION 2
 
 /* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
 #define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */
@@ -115,7 +118,10 @@ int misti_destroy(misti_ctx* ctx);
 
 /* Issue work on an existing hipStream_t (e.g. PyTorch's current stream) instead
  * of the context's own; pass NULL to go back.  The stream must belong to the
- * context's device. */
+ * context's device.  When the stream actually changes, an event recorded on the old
+ * stream is waited for on the new one (hipStreamWaitEvent): work already issued on
+ * this context completes before anything issued later starts, because all batches of
+ * a context share its workspaces (chain table, rates, trunk records). */
 int misti_set_stream(misti_ctx* ctx, void* hip_stream);
 /* The hipStream_t the context currently issues on (its own non-blocking stream unless replaced):
  * lets a caller order its own work or events against the batch (bench.py wraps it for RCCL). */
@@ -129,6 +135,14 @@ int misti_sync(misti_ctx* ctx);
  * n_cand >= 0, n_rep >= 0 (n_rep == 0: spectrum only; llk may be NULL).
  *   split_time [n_cand]            fractional allowed (:89-99)
  *   params     [n_cand][n_param]   NULL allowed when n_param == 0
+ *   band_bounds [n_cand][n_band][2] or NULL   per-candidate (start, end) of every -mi band, replacing
+ *                                  the model's; end == -1 = the candidate's split index.  This is the
+ *                                  reference's own recommended sweep (README.md:110-115: `-mi 1 0 {mc} ..
+ *                                  -mi 1 {mc} {st} .. ::: st 20 21 .. ::: mc 8 9 ..`), where a band boundary
+ *                                  varies independently of the split.  A candidate whose bounds violate
+ *                                  SetModel's checks (:237-255: start >= sample date, start < end, no
+ *                                  overlap within a population) gets status MISTI_BAD_STRUCTURE.
+ *                                  NULL = the model's bounds for every candidate.
  *   jsfs       [n_rep][8]          rows "total + 7 classes" (SetJAFS :208-211);
  *                                  llh_const (:217-227) is computed inside
  *   llk        [n_cand][n_rep]     -inf on a soft failure (:572,:578)
@@ -142,7 +156,7 @@ int misti_sync(misti_ctx* ctx);
  *   status     [n_cand]     or NULL   MISTI_OK / MISTI_NEG_PARAM / ...
  */
 int misti_eval_batch(misti_ctx* ctx, int64_t n_cand,
-                     const double* split_time, const double* params,
+                     const double* split_time, const double* params, const int32_t* band_bounds,
                      int64_t n_rep, const double* jsfs,
                      double* llk, double* jafs, double* lc, double* pr, int32_t* status);
 
@@ -150,7 +164,7 @@ int misti_eval_batch(misti_ctx* ctx, int64_t n_cand,
  * context's device; asynchronous on the context's stream (call misti_sync or
  * synchronise the stream yourself).  This is the form bench.py times. */
 int misti_eval_batch_dev(misti_ctx* ctx, int64_t n_cand,
-                         const double* d_split_time, const double* d_params,
+                         const double* d_split_time, const double* d_params, const int32_t* d_band_bounds,
                          int64_t n_rep, const double* d_jsfs,
                          double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status);
 
@@ -172,6 +186,29 @@ int misti_argmax_dev(misti_ctx* ctx, int64_t n_cand, int64_t n_rep, const double
  * the reference's own log-likelihood is not determined to 1e-9.
  * Copies n_cand doubles to HOST memory and synchronises the stream. */
 int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
+
+/* ---- solver trace (parity diagnostics) ---------------------------------------- */
+/* The reference's corrected rates are DEFINED by where SciPy's trust-region iteration stops
+ * (CorrectLambda.py:85,260,303,305 -> scipy.optimize.least_squares); tests compare that iteration
+ * itself.  When enabled, every batch of this context records per candidate and interval one word
+ *     bits 0-15  nfev        residual evaluations SciPy would count (OptimizeResult.nfev)
+ *     bits 16-19 status      SciPy's termination code: 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol+xtol
+ *     bits 20-23 kind        0 no solve (trueEPS / T == 0), 1 closed form (SolveNoMigration1 :213-235,
+ *                            cpfit post-split :366), 2 bounded TRF (SolveNoMigration :253-264, FitSinglePop
+ *                            :82-92), 3 unbounded TRF (SolveLambdaSystem :299-305)
+ * for intervals 0..numT (row numT is used only by a fractional split); and, for batches of at most
+ * MISTI_TRACE_MAX_CAND candidates, the trial points of the unbounded solves (stretched to the unit
+ * interval as the reference does, :293-298), at most MISTI_TRACE_MAX_ITER per interval.
+ * misti_last_solver_trace copies to HOST memory and synchronises the stream:
+ *   trace    [n_cand][numT+1]                              (n_cand = size of the last batch)
+ *   iterates [numT][MISTI_TRACE_MAX_ITER][2] or NULL       trial points of candidate `cand`'s chain
+ *                                                          (NaN beyond nfev); row = interval on the
+ *                                                          shared grid; the interval shortened by a
+ *                                                          fractional split is not recorded */
+#define MISTI_TRACE_MAX_CAND 64
+#define MISTI_TRACE_MAX_ITER 200
+int misti_enable_solver_trace(misti_ctx* ctx, int on);
+int misti_last_solver_trace(misti_ctx* ctx, int64_t n_cand, int32_t* trace, int64_t cand, double* iterates);
 
 /* ---- forward map (data generation; TestModel route) --------------------------- */
 /* Replaces MigrationInference.CoalescentRates (MigrationInference.py:542-564) and

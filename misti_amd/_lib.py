@@ -18,9 +18,11 @@ STATUS_TEXT = {
     3: "Infinite coalescent time (two populations in the last interval)",
     4: "Split time / band / pulse structure invalid for this candidate",
     5: "Non-finite intermediate or iteration cap",
-    6: "Stiff interval (rate x length > 128) beyond the series path",
+    6: "Stiff interval: the contour solver (rate x length > 96) did not converge",
 }
 MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
+ABI_VERSION = 2
+TRACE_MAX_CAND, TRACE_MAX_ITER = 64, 200
 
 
 class Band(C.Structure):
@@ -55,10 +57,12 @@ SYMBOLS = {
     "misti_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "misti_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "misti_sync": (C.c_int, [C.c_void_p]),
-    "misti_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    "misti_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "misti_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    "misti_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_enable_solver_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "misti_last_solver_trace": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "misti_llk_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "misti_forward_rates": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_forward_rates_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -82,10 +86,15 @@ def load(build_if_missing=True):
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path):
-        if not build_if_missing:
-            raise MistiError(-3, "libmisti_hip.so is not built (%s); run misti_amd.build.build()" % path)
-        _build.build()
+    if os.environ.get("MISTI_LIB"):
+        path = os.environ["MISTI_LIB"]          # an explicitly chosen build (kernel experiments); never rebuilt
+    elif build_if_missing and _build.have_hipcc():
+        _build.build()                           # no-op when the library is newer than every source and header
+    elif not os.path.exists(path):
+        raise MistiError(-3, "libmisti_hip.so is not built (%s) and hipcc is not available; run misti_amd.build.build()" % path)
+    elif _build.stale():
+        import warnings
+        warnings.warn("libmisti_hip.so is older than its sources and hipcc is not available to rebuild it", RuntimeWarning)
     # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64; if this
     # library is loaded first it binds the system ROCm runtime and a later `import torch` brings a second one into
     # the process (observed: torch.cuda then intermittently reports "No HIP GPUs are available", and stream or
@@ -100,8 +109,9 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.misti_abi_version() != 1:
-        raise MistiError(-1, "ABI version mismatch")
+    if lib.misti_abi_version() != ABI_VERSION:
+        raise MistiError(-1, "ABI version mismatch: %s is version %d, this binding expects %d (rebuild: python -m misti_amd.build --force)"
+                         % (path, lib.misti_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

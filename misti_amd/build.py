@@ -20,6 +20,14 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def have_hipcc():
+    try:
+        hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def stale():
     if not os.path.exists(LIB):
         return True
@@ -27,9 +35,11 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False, extra=()):
-    """Compile the kernels and the C-ABI layer into misti_amd/csrc/libmisti_hip.so."""
-    if not force and not stale():
+def build(force=False, verbose=False, extra=(), out=None):
+    """Compile the kernels and the C-ABI layer into misti_amd/csrc/libmisti_hip.so (or `out`: an experimental
+    variant, loaded with MISTI_LIB=<path>; -D switches go in `extra`)."""
+    target = out or LIB
+    if not force and not out and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
@@ -39,14 +49,18 @@ def build(force=False, verbose=False, extra=()):
     if os.environ.get("MISTI_STAMP"):          # diagnostic build: per-section cycle stamps in the correction kernel
         cmd += ["-DMISTI_STAMP=1"]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
+    cmd += ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True,
-                extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else []))
+    out = None
+    if "--out" in sys.argv:
+        out = os.path.abspath(sys.argv[sys.argv.index("--out") + 1])
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    print(build(force="--force" in sys.argv, verbose=True, out=out,
+                extra=defs + (["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])))

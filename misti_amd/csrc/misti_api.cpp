@@ -78,7 +78,12 @@ struct misti_ctx {
     int32_t batch_seq = 0;
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
-    DevBuf st_split, st_params, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
+    DevBuf st_split, st_params, st_bounds, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
+    bool trace = false;                 // solver trace (misti_enable_solver_trace)
+    DevBuf ws_solver, ws_iters;         // per chain / per candidate solver words; trial points of small batches
+    int64_t trace_n = 0, trace_iter_cap = 0;   // candidates / chains covered by the trace of the last batch
+    const int32_t* trace_of = nullptr;  // candidate -> chain of the last batch (device)
+    hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms[3] = {0, 0, 0};
@@ -149,22 +154,58 @@ int validate_model(const misti_model_t* m) {
     return 0;
 }
 
-int record_begin(misti_ctx* c, int which, hipEvent_t* a, hipEvent_t* b) {
-    if (!c->timing) return 0;
-    HIP_TRY(hipEventCreate(a));
-    HIP_TRY(hipEventCreate(b));
-    HIP_TRY(hipEventRecord(*a, c->stream));
-    (void)which;
+// Fold the finished event pairs of one stage into its totals (all of them when `all`, else only while more than
+// `keep` are pending: a caller that enables timing and never reads it must not accumulate events without bound).
+int drain_pending(misti_ctx* c, int which, bool all, size_t keep = 256) {
+    auto& v = c->pending[which];
+    size_t done = 0;
+    while (done < v.size() && (all || v.size() - done > keep)) {
+        HIP_TRY(hipEventSynchronize(v[done].second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, v[done].first, v[done].second));
+        c->ms[which] += t;
+        (void)hipEventDestroy(v[done].first);
+        (void)hipEventDestroy(v[done].second);
+        ++done;
+    }
+    v.erase(v.begin(), v.begin() + (long)done);
     return 0;
 }
-int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
+int record_begin(misti_ctx* c, int which, hipEvent_t* a, hipEvent_t* b) {
+    *a = *b = nullptr;
     if (!c->timing) return 0;
-    HIP_TRY(hipEventRecord(b, c->stream));
+    if (int r = drain_pending(c, which, false)) return r;
+    hipError_t e = hipEventCreate(a);
+    if (e == hipSuccess) e = hipEventCreate(b);
+    if (e == hipSuccess) e = hipEventRecord(*a, c->stream);
+    if (e != hipSuccess) {
+        if (*a) (void)hipEventDestroy(*a);
+        if (*b) (void)hipEventDestroy(*b);
+        *a = *b = nullptr;
+        return fail(MISTI_E_HIP, "timing events: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+// which < 0: the stage failed - drop the pair
+int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
+    if (!a) return 0;
+    hipError_t e = which >= 0 ? hipEventRecord(b, c->stream) : hipErrorUnknown;
+    if (e != hipSuccess) {
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        return which >= 0 ? fail(MISTI_E_HIP, "hipEventRecord: %s", hipGetErrorString(e)) : 0;
+    }
     c->pending[which].push_back({a, b});
     return 0;
 }
+// a launch between record_begin and record_end failed: release the pair, keep the error
+#define HIP_TRY_EV(expr, a, b)                                                            \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) { (void)record_end(c, -1, a, b); return fail(MISTI_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
 
-int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int64_t n_rep, const double* d_jsfs,
+int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
             double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status) {
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
@@ -204,6 +245,29 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
         cb.trunk_cap = (int64_t)ntr;
         cb.hint = c->hint_dev;
+        cb.bounds = c->dm.n_band > 0 ? d_bounds : nullptr;
+        cb.solver = cb.tail_solver = cb.cand_solver = nullptr;
+        cb.iters = nullptr;
+        cb.iter_cap = 0;
+        c->trace_n = 0;
+        c->trace_iter_cap = 0;
+        if (c->trace) {
+            HIP_TRY(c->ws_solver.reserve((nc * numT + nc + nc * (numT + 1)) * sizeof(int32_t)));
+            HIP_TRY(hipMemsetAsync(c->ws_solver.p, 0, (nc * numT + nc + nc * (numT + 1)) * sizeof(int32_t), c->stream));
+            cb.solver = c->ws_solver.as<int32_t>();
+            cb.tail_solver = cb.solver + nc * numT;
+            cb.cand_solver = cb.tail_solver + nc;
+            c->trace_n = n_cand;
+            c->trace_of = cb.of;
+            if (n_cand <= MISTI_TRACE_MAX_CAND) {
+                const size_t it_n = nc * numT * MISTI_TRACE_MAX_ITER * 2;
+                HIP_TRY(c->ws_iters.reserve(it_n * sizeof(double)));
+                HIP_TRY(hipMemsetAsync(c->ws_iters.p, 0xff, it_n * sizeof(double), c->stream));      // all-ones = NaN: "no such iterate"
+                cb.iters = c->ws_iters.as<double>();
+                cb.iter_cap = n_cand;
+                c->trace_iter_cap = n_cand;
+            }
+        }
     }
     // Launch shape of kernel 1 depends on the number of chains, which lives on the device: discover_kernel drops
     // {chains, candidates, batch tag} into pinned memory.  A batch of the same size as the previous one on this
@@ -228,8 +292,8 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const bool llk_inline = n_rep > 0 && n_rep <= misti::LLK_INLINE_MAX;
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream));
-    HIP_TRY(misti::launch_chain_discovery(n_cand, c->dm.n_param, d_params, d_split, c->dm.numT, cb, c->stream));
+    HIP_TRY_EV(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream), a, b);
+    HIP_TRY_EV(misti::launch_chain_discovery(n_cand, c->dm.n_param, cb.bounds ? c->dm.n_band : 0, d_params, d_split, c->dm.numT, cb, c->stream), a, b);
     if (est_chains < 0 && hint && misti::correct_cands_per_wave(n_cand) > 1) {
         const auto t0 = std::chrono::steady_clock::now();
         while (hint[2] != cb.seq && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) std::this_thread::yield();
@@ -238,19 +302,19 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     int cpw_chains = 1;
     bool follow = false;
     shape(est_chains, cpw_chains, follow);
-    HIP_TRY(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, c->stream));
+    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->stream), a, b);
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
-    if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
-    HIP_TRY(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                   n_rep, d_jsfs, d_consts, d_llk, follow, c->stream));
+    if (int r = record_begin(c, 1, &a, &b)) return r;
+    HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
+                                      n_rep, d_jsfs, d_consts, d_llk, follow, c->stream), a, b);
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {
         if (int r = record_begin(c, 2, &a, &b)) return r;
-        HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, d_consts, d_llk, c->unfolded, c->stream));
+        HIP_TRY_EV(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, d_consts, d_llk, c->unfolded, c->stream), a, b);
         if (int r = record_end(c, 2, a, b)) return r;
         if (c->timing) c->launches[2] += 1;
     }
@@ -294,6 +358,8 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
     if (ndev <= 0) return fail(MISTI_E_NODEV, "no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(MISTI_E_ARG, "device %d out of range (0..%d)", device, ndev - 1);
     misti_ctx* c = nullptr;
+    // every failure after `new` releases what the context already owns (stream, pinned hint, device buffers)
+    struct Guard { misti_ctx*& c; bool keep = false; ~Guard() { if (!keep && c) { misti_destroy(c); c = nullptr; } } } guard{c};
     try {
         c = new misti_ctx();
         const misti::HostTables& t = host_tables();
@@ -346,7 +412,7 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         static const int want1[8][8] = {{-6, 0, 0, 0, 0, 0, 0, 0}, {1, -3, 0, 0, 0, 0, 0, 0}, {4, 0, -3, 0, 0, 0, 0, 0}, {1, 0, 0, -3, 0, 0, 0, 0},
                                         {0, 2, 1, 0, -1, 0, 0, 0}, {0, 0, 1, 2, 0, -1, 0, 0}, {0, 1, 0, 1, 0, 0, -1, 0}, {0, 0, 1, 0, 0, 0, 0, -1}};
         for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j)
-            if (t.gen1[i][j] != want1[i][j]) { delete c; return fail(MISTI_E_ARG, "one-population generator mismatch at (%d,%d)", i, j); }
+            if (t.gen1[i][j] != want1[i][j]) return fail(MISTI_E_ARG, "one-population generator mismatch at (%d,%d)", i, j);
 
         const int numT = model->numT;
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -382,9 +448,9 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         for (int p = 0; p < model->n_pulse; ++p) d.pulses[p] = model->pulses[p];
         c->unfolded = (model->flags & MISTI_UNFOLDED) ? 1 : 0;
     } catch (const std::exception& e) {
-        delete c;
         return fail(MISTI_E_ARG, "misti_create: %s", e.what());
     }
+    guard.keep = true;
     *out = c;
     return 0;
 }
@@ -393,9 +459,10 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->st_split, &c->st_params, &c->st_jsfs,
-                    &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->ws_solver, &c->ws_iters,
+                    &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
+    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
     for (int w = 0; w < 3; ++w)
         for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -406,7 +473,16 @@ int misti_destroy(misti_ctx* c) {
 
 int misti_set_stream(misti_ctx* c, void* s) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
-    c->stream = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    hipStream_t next = s ? static_cast<hipStream_t>(s) : c->own_stream;
+    if (next == c->stream) return 0;
+    // All batches of a context share its workspaces (chain table, rates, trunk records, the pinned hint) and the
+    // *_dev calls are asynchronous: what was issued on the old stream must finish before anything issued on the new
+    // one starts, or batch N+1 overwrites what batch N is still reading.
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->order_ev) HIP_TRY(hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->order_ev, c->stream));
+    HIP_TRY(hipStreamWaitEvent(next, c->order_ev, 0));
+    c->stream = next;
     return 0;
 }
 
@@ -423,10 +499,10 @@ int misti_sync(misti_ctx* c) {
     return 0;
 }
 
-int misti_eval_batch_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int64_t n_rep,
+int misti_eval_batch_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep,
                          const double* d_jsfs, double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
-    return run_dev(c, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs, d_lc, d_pr, d_status);
+    return run_dev(c, n_cand, d_split, d_params, d_bounds, n_rep, d_jsfs, d_llk, d_jafs, d_lc, d_pr, d_status);
 }
 
 int misti_llk_dev(misti_ctx* c, int64_t n_cand, const double* d_jafs, const int32_t* d_status, int64_t n_rep, const double* d_jsfs, double* d_llk) {
@@ -439,7 +515,7 @@ int misti_llk_dev(misti_ctx* c, int64_t n_cand, const double* d_jafs, const int3
     HIP_TRY(misti::launch_llh_const(n_rep, d_jsfs, c->consts.as<double>(), c->unfolded, c->stream));
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 2, &a, &b)) return r;
-    HIP_TRY(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, c->consts.as<double>(), d_llk, c->unfolded, c->stream));
+    HIP_TRY_EV(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, c->consts.as<double>(), d_llk, c->unfolded, c->stream), a, b);
     if (int r = record_end(c, 2, a, b)) return r;
     if (c->timing) c->launches[2] += 1;
     return 0;
@@ -456,7 +532,7 @@ int misti_argmax_dev(misti_ctx* c, int64_t n_cand, int64_t n_rep, const double* 
     return 0;
 }
 
-int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, int64_t n_rep, const double* jsfs,
+int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
                      double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
@@ -473,6 +549,12 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
         HIP_TRY(c->st_params.reserve(nc * P * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(c->st_params.p, params, nc * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
+    const bool with_bounds = band_bounds && c->dm.n_band > 0;
+    if (with_bounds) {
+        const size_t bytes = nc * 2 * (size_t)c->dm.n_band * sizeof(int32_t);
+        HIP_TRY(c->st_bounds.reserve(bytes));
+        HIP_TRY(hipMemcpyAsync(c->st_bounds.p, band_bounds, bytes, hipMemcpyHostToDevice, c->stream));
+    }
     if (nr) {
         HIP_TRY(c->st_jsfs.reserve(nr * 8 * sizeof(double)));
         HIP_TRY(hipMemcpyAsync(c->st_jsfs.p, jsfs, nr * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -486,7 +568,8 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
         HIP_TRY(c->st_pr.reserve(pr_n * sizeof(double)));
         HIP_TRY(hipMemsetAsync(c->st_pr.p, 0, pr_n * sizeof(double), c->stream));
     }
-    int r = run_dev(c, n_cand, c->st_split.as<double>(), P > 0 ? c->st_params.as<double>() : nullptr, n_rep,
+    int r = run_dev(c, n_cand, c->st_split.as<double>(), P > 0 ? c->st_params.as<double>() : nullptr,
+                    with_bounds ? c->st_bounds.as<int32_t>() : nullptr, n_rep,
                     nr ? c->st_jsfs.as<double>() : nullptr, nr ? c->st_llk.as<double>() : nullptr, c->st_jafs.as<double>(),
                     lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
     if (r) return r;
@@ -552,6 +635,37 @@ int misti_last_diag(misti_ctx* c, int64_t n_cand, double* max_rate_x_len) {
     return 0;
 }
 
+int misti_enable_solver_trace(misti_ctx* c, int on) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    c->trace = on != 0;
+    if (!c->trace) { c->trace_n = 0; c->trace_iter_cap = 0; }
+    return 0;
+}
+
+int misti_last_solver_trace(misti_ctx* c, int64_t n_cand, int32_t* trace, int64_t cand, double* iterates) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (!c->trace || c->trace_n == 0) return fail(MISTI_E_ARG, "no solver trace: enable it before the batch (misti_enable_solver_trace)");
+    if (n_cand != c->trace_n) return fail(MISTI_E_ARG, "the traced batch had %lld candidates, not %lld", (long long)c->trace_n, (long long)n_cand);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nc = (size_t)n_cand, numT = (size_t)c->dm.numT;
+    if (trace) {
+        const int32_t* src = c->ws_solver.as<int32_t>() + nc * numT + nc;
+        HIP_TRY(hipMemcpyAsync(trace, src, nc * (numT + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (iterates) {
+        if (c->trace_iter_cap == 0) return fail(MISTI_E_LIMIT, "iterates are recorded for batches of at most %d candidates", MISTI_TRACE_MAX_CAND);
+        if (cand < 0 || cand >= n_cand) return fail(MISTI_E_ARG, "candidate %lld out of range", (long long)cand);
+        int32_t ch = -1;
+        HIP_TRY(hipMemcpyAsync(&ch, c->trace_of + cand, sizeof ch, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (ch < 0 || ch >= c->trace_iter_cap) return fail(MISTI_E_ARG, "candidate %lld has no chain", (long long)cand);
+        const size_t per = numT * MISTI_TRACE_MAX_ITER * 2;
+        HIP_TRY(hipMemcpyAsync(iterates, c->ws_iters.as<double>() + (size_t)ch * per, per * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int misti_enable_timing(misti_ctx* c, int on) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     c->timing = on != 0;
@@ -562,15 +676,7 @@ int misti_kernel_times(misti_ctx* c, double ms[3], int64_t launches[3], int rese
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     for (int w = 0; w < 3; ++w) {
-        for (auto& pr : c->pending[w]) {
-            HIP_TRY(hipEventSynchronize(pr.second));
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
-            c->ms[w] += t;
-            (void)hipEventDestroy(pr.first);
-            (void)hipEventDestroy(pr.second);
-        }
-        c->pending[w].clear();
+        if (int r = drain_pending(c, w, true)) return r;
         if (ms) ms[w] = c->ms[w];
         if (launches) launches[w] = c->launches[w];
         if (reset) { c->ms[w] = 0; c->launches[w] = 0; }

@@ -69,7 +69,18 @@ struct ChainBufs {
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
     int32_t* hint;          // host-pinned [3] or NULL: {chains, candidates, batch tag}, written by the last block of discover_kernel
     int32_t seq;            // this batch's tag
+    const int32_t* bounds;  // [n][n_band][2] per-candidate (start, end) of every band, or NULL: the model's
+    // solver trace (misti_enable_solver_trace), all NULL when off
+    int32_t* solver;        // [n][numT] per chain: packed word of interval t (nfev | status << 16 | kind << 20)
+    int32_t* tail_solver;   // [n] per candidate with a fractional split: the shortened interval
+    int32_t* cand_solver;   // [n][numT+1] per candidate, assembled by the spectrum kernel (+ post-split solves)
+    double* iters;          // [iter_cap][numT][MISTI_TRACE_MAX_ITER][2] trial points of the unbounded solves, or NULL
+    int64_t iter_cap;       // chains the iterate buffer holds
 };
+
+__host__ __device__ __forceinline__ int32_t solver_word(int nfev, int status, int kind) {
+    return (int32_t)((nfev & 0xffff) | ((status & 15) << 16) | ((kind & 15) << 20));
+}
 
 __device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.of[cand]; }
 __device__ __forceinline__ int chain_len(const ChainBufs& cb, int64_t ch) { return cb.slot_len[cb.chain_slot[ch]]; }
@@ -83,11 +94,11 @@ int64_t trunk_capacity(int64_t n_cand);
 uint32_t chain_table_size(int64_t n_cand);
 hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
                           int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
-hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream);
+hipError_t launch_chain_discovery(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream);
 int correct_cands_per_wave(int64_t n_items);
 bool trunk_follows(int cpw_chains, int64_t trunk_cap);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, hipStream_t stream);
+                          int cpw, bool follow, int64_t est_chains, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
                            int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream);

@@ -83,6 +83,20 @@ __device__ __forceinline__ double gbcast(double v, int j) {
     return __shfl(v, (lane_id() - lane_id() % GROUP) + j, 64);     // GROUP = 6: ten items per wave, lanes 60-63 idle
 }
 
+// Hand-over words in LDS between the two waves of a workgroup (correct_follow_kernel).  The pointers reach the
+// device functions as generic pointers and a volatile access through a generic pointer is a FLAT instruction with
+// system-scope cache bits followed by a wait for every outstanding global store; through an LDS-typed pointer it is a
+// plain ds_read / ds_write.  LDS serves one wave's accesses in issue order, so "data, then count" needs no more than
+// the compiler keeping that order (and lgkmcnt for the reader's data dependence).
+typedef __attribute__((address_space(3))) int lds_i32_t;
+__device__ __forceinline__ void lds_put(volatile int* p, int v) { *(volatile lds_i32_t*)(lds_i32_t*)p = v; }
+__device__ __forceinline__ int lds_get(const volatile int* p) { return *(const volatile lds_i32_t*)(lds_i32_t*)p; }
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the LDS writes before are done; no wait for global stores
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void lds_fence() {
     // one wave owns its LDS slice: ordering only has to be kept by the compiler
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -123,6 +137,7 @@ struct Model {
     const double* par;     // [n_param] of this candidate
     int split;
     double pv[4];          // the first parameters, cached in registers (a sweep has 1-3)
+    const int32_t* bb = nullptr;   // [n_band][2] this candidate's (start, end) of every band, or NULL: the model's
     __device__ __forceinline__ void cache() { for (int i = 0; i < 4; ++i) pv[i] = (i < m->n_param) ? par[i] : 0.0; }
     __device__ __forceinline__ double param(int i) const {
         return i == 0 ? pv[0] : i == 1 ? pv[1] : i == 2 ? pv[2] : i == 3 ? pv[3] : par[i];
@@ -131,8 +146,10 @@ struct Model {
         mu0 = 0.0; mu1 = 0.0;
         for (int b = 0; b < m->n_band; ++b) {
             const misti_band_t& B = m->bands[b];
-            int end = B.end < 0 ? split : B.end;
-            if (t >= B.start && t < end) {
+            const int start = bb ? bb[2 * b] : B.start;
+            int end = bb ? bb[2 * b + 1] : B.end;
+            if (end < 0) end = split;
+            if (t >= start && t < end) {
                 double v = B.param >= 0 ? param(B.param) : B.value;
                 if (B.pop == 0) mu0 = v; else mu1 = v;
             }
@@ -561,7 +578,8 @@ template <int N> __device__ __forceinline__ double select_step(const double x[N]
 }
 
 // fun(x, f): N residuals of N unknowns.  x is updated in place.
-template <int N, class Fun> __device__ __forceinline__ void trf_bounded(Fun fun, double x[N], double lb) {
+// Returns the solver word (nfev | SciPy status << 16 | kind 2 << 20, see include/misti_hip.h).
+template <int N, class Fun> __device__ __forceinline__ int32_t trf_bounded(Fun fun, double x[N], double lb) {
     auto eval = [&](const double xx[N], double f[N], double J[N][N]) {
         fun(xx, f);
         for (int j = 0; j < N; ++j) {
@@ -638,6 +656,7 @@ template <int N, class Fun> __device__ __forceinline__ void trf_bounded(Fun fun,
             grad();
         }
     }
+    return solver_word(nfev, term, 2);
 }
 
 // ExpectedCoalTimeOnePop, CorrectLambda.py:67-72 (note the lam > 100 clamp)
@@ -764,7 +783,28 @@ __device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu
 // ----------------------------------------------------------- the kernels ----
 // Candidate structure shared by both kernels: fractional split (:89-99), negative
 // parameter guard (:569-572), split beyond the grid.
-__device__ __forceinline__ int setup_candidate(const DevModel& m, double st, const double* par, Grid& G) {
+// SetModel's checks on the bands as this candidate sees them (MigrationInference.py:237-255): start >= sample
+// date, start < end (end == -1: the candidate's split index), no overlap within a population.
+__device__ __forceinline__ bool bands_valid(const DevModel& m, const int32_t* bb, int split) {
+    bool ok = true;
+    for (int b = 0; b < m.n_band; ++b) {
+        const int sb = bb ? bb[2 * b] : m.bands[b].start;
+        int eb = bb ? bb[2 * b + 1] : m.bands[b].end;
+        if (eb < -1 || eb > m.numT + 1) ok = false;
+        if (eb < 0) eb = split;
+        if (sb < m.sample_date || eb <= sb) ok = false;
+        for (int c = 0; c < b; ++c) {
+            if (m.bands[c].pop != m.bands[b].pop) continue;
+            const int sc = bb ? bb[2 * c] : m.bands[c].start;
+            int ec = bb ? bb[2 * c + 1] : m.bands[c].end;
+            if (ec < 0) ec = split;
+            if (sb < ec && sc < eb) ok = false;
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int setup_candidate(const DevModel& m, double st, const double* par, Grid& G, const int32_t* bb = nullptr) {
     int status = MISTI_OK;
     G.times = m.times; G.lh = m.lh; G.numT0 = m.numT;
     double fl = floor(st);
@@ -776,7 +816,9 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
         if (s > m.numT - 2) status = MISTI_BAD_STRUCTURE;
         else { G.ins = s; G.split = s + 1; G.numT = m.numT + 1; }
     }
-    for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
+    if (status == MISTI_OK && m.n_band > 0 && !bands_valid(m, bb, G.split)) status = MISTI_BAD_STRUCTURE;
+    // construction errors (PrintError + exit in the reference's __init__/SetModel) come before the guard of JAFSLikelihood (:569-572)
+    if (status == MISTI_OK) for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
     if (status == MISTI_OK && G.split >= G.numT) status = MISTI_INF_COAL;
     return status;
 }
@@ -861,7 +903,7 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 template <bool CPFIT, int GROUP, bool TAIL>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
-                  int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr) {
+                  int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr) {
     const int lane = lane_id();
     const int sub = lane % GROUP;
     const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
@@ -893,19 +935,25 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     double* lc_w;     // lc_w[2 t + k]        corrected rates of interval t
     double* tr_w;     // tr_w[6 (t + 1) + j]  pair state after interval t
     PairState ps;
+    const int32_t* bb = cb.bounds ? cb.bounds + cand * 2 * m.n_band : nullptr;
+    int32_t* sv_w = nullptr;   // sv_w[t]  solver word of interval t (trace on)
+    double* it_w = nullptr;    // it_w[(t * MISTI_TRACE_MAX_ITER + i) * 2 + k]  trial points of the unbounded solve of interval t
     if (!TAIL) {
         status = MISTI_OK;
         for (int i = 0; i < m.n_param; ++i) if (par[i] < 0) status = MISTI_NEG_PARAM;
         G.numT0 = m.numT; G.numT = m.numT; G.split = chain_len(cb, slot); G.ins = -1; G.frac = 0.0;
+        if (cb.solver) sv_w = cb.solver + slot * (int64_t)m.numT;
+        if (cb.iters && slot < cb.iter_cap) it_w = cb.iters + slot * (int64_t)m.numT * MISTI_TRACE_MAX_ITER * 2;
         lc_w = cb.lc + slot * (int64_t)m.numT * 2;
         tr_w = cb.trace + slot * (int64_t)(m.numT + 1) * 6;
         ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
         ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
         if (sub == 0) { tr_w[0] = 1; tr_w[1] = 0; tr_w[2] = 0; tr_w[3] = 1; tr_w[4] = 0; tr_w[5] = 0; }
     } else {
-        status = setup_candidate(m, split_time[cand], par, G);
+        status = setup_candidate(m, split_time[cand], par, G, bb);
         if (sub == 0) cb.tail_status[cand] = MISTI_OK;
         if (status != MISTI_OK || G.ins < 0) return;               // nothing to do: no fractional split
+        if (cb.tail_solver) sv_w = cb.tail_solver + cand - G.ins;
         const int64_t ch = chain_of(cb, cand);
         if (cb.fail_t[ch] < G.ins) return;                         // the chain failed before this candidate's tail
         t = G.ins;
@@ -916,6 +964,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     }
     G.times = lds; G.lh = lds + (m.numT - 1);
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
+    mod.bb = bb;
     mod.cache();
     const bool correct = !(m.flags & MISTI_TRUE_EPS);
     const int max_nfev = 200;                    // 100 * n (least_squares.py)
@@ -930,8 +979,8 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     bool first = false, in_solve = false, have_sv = false;
     Svd2 sv;
 
-    auto finish_interval = [&](double lc0, double lc1) -> bool {       // :345-350; false = correction failed
-        if (sub == 0) { lc_w[2 * t] = lc0; lc_w[2 * t + 1] = lc1; }
+    auto finish_interval = [&](double lc0, double lc1, int32_t word) -> bool {       // :345-350; false = correction failed
+        if (sub == 0) { lc_w[2 * t] = lc0; lc_w[2 * t + 1] = lc1; if (sv_w) sv_w[t] = word; }
         if (!(lc0 > 0) || !(lc1 > 0)) {
             status = (isnan(lc0) || isnan(lc1)) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
             return false;
@@ -943,8 +992,8 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         if (!TAIL && lc_sh) {
             // hand the interval to the trunk wave of this workgroup (correct_follow_kernel): rates, then the count
             if (sub == 0) { lc_sh[2 * t] = lc0; lc_sh[2 * t + 1] = lc1; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (sub == 0) flags[0] = t + 1;
+            lds_order();
+            if (sub == 0) lds_put(flags, t + 1);
         }
         ++t;
         return true;
@@ -957,6 +1006,21 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 #define STAMP(acc)
 #endif
     bool active = status == MISTI_OK;
+    if (pre) {
+        // What an interval needs that does not depend on the recursion - migration rates, pulse, exp(-lh T) of both
+        // genomes - for all intervals at once, one interval per lane, instead of a band-table walk and two exponentials on
+        // the critical path of every interval.  Same expressions as below, so the same bits.
+        if (active)
+            for (int tt = lane; tt < G.split; tt += 64) {
+                double a0, a1, b0, b1;
+                mod.mig(tt, a0, a1);
+                mod.pulse(tt, b0, b1);
+                const double Tt = G.T(tt);
+                double* q = pre + 6 * tt;
+                q[0] = a0; q[1] = a1; q[2] = b0; q[3] = b1; q[4] = exp(-G.lhk(tt, 0) * Tt); q[5] = exp(-G.lhk(tt, 1) * Tt);
+            }
+        lds_fence();
+    }
 #ifdef MISTI_STAMP
     c_t0 = clock64();
 #endif
@@ -964,29 +1028,31 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         if (!in_solve) {
             // ---- advance over intervals until one needs the iterative solver ----------
             while (t < G.split) {
-                double pu0, pu1, mu0, mu1;
-                mod.pulse(t, pu0, pu1);
-                mod.mig(t, mu0, mu1);
+                double pu0, pu1, mu0, mu1, eh0 = 0.0, eh1 = 0.0;
+                if (pre) { const double* q = pre + 6 * t; mu0 = q[0]; mu1 = q[1]; pu0 = q[2]; pu1 = q[3]; eh0 = q[4]; eh1 = q[5]; }
+                else { mod.pulse(t, pu0, pu1); mod.mig(t, mu0, mu1); }
                 pulse_pairs(ps, pu0, pu1);                                              // :315-323
                 double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
-                if (!correct) { if (!finish_interval(lh0, lh1)) break; continue; }       // :325-326
+                if (!correct) { if (!finish_interval(lh0, lh1, 0)) break; continue; }    // :325-326
                 T = G.T(t);
                 const double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
                 const double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
                 if (m.mixture_th > 0.0) {                                               // CorrectLambda.py:267-272 (threshold 0 never fires)
                     double mix = 0.0;
                     for (int i = 0; i < 3; ++i) { double d = ps.p[0][i] / s0 - ps.p[1][i] / s1; mix += d * d; }
-                    if (sqrt(mix) < m.mixture_th) { finish_interval(-1.0, -1.0); break; }
+                    if (sqrt(mix) < m.mixture_th) { finish_interval(-1.0, -1.0, 0); break; }
                 }
                 if (mu0 + mu1 < 1e-10) {
                     double lc0, lc1;
+                    int32_t word = solver_word(0, 0, 1);
                     if (CPFIT) {
                         // SolveNoMigration1 :213-235
                         double A1 = ps.p[0][0] / s0, A2 = ps.p[0][1] / s0, A3 = ps.p[1][0] / s1, A4 = ps.p[1][1] / s1;
                         double C1 = ps.p[0][2] / s0, C2 = ps.p[1][2] / s1;
                         double D = A1 * A4 - A2 * A3;
                         double B1 = A4 / D, B2 = -A2 / D, B3 = -A3 / D, B4 = A1 / D;
-                        double X1 = exp(-lh0 * T) - C1, X2 = exp(-lh1 * T) - C2;
+                        if (!pre) { eh0 = exp(-lh0 * T); eh1 = exp(-lh1 * T); }
+                        double X1 = eh0 - C1, X2 = eh1 - C2;
                         double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
                         if (y0 > 0 && y1 > 0) { lc0 = -log(y0) / T; lc1 = -log(y1) / T; }
                         else { lc0 = lc1 = -1.0; }
@@ -1005,25 +1071,27 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                             }
                         };
                         double xx[2] = {lh0, lh1};
-                        trf_bounded<2>(resid, xx, 0.01 * fmin(lh0, lh1));
+                        word = trf_bounded<2>(resid, xx, 0.01 * fmin(lh0, lh1));
                         lc0 = xx[0]; lc1 = xx[1];
                     }
                     double e0 = exp(-lc0 * T), e1 = exp(-lc1 * T);
                     for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
-                    if (!finish_interval(lc0, lc1)) break;
+                    if (!finish_interval(lc0, lc1, word)) break;
                     continue;
                 }
                 // migrating interval: set the 2x2 problem up (:278-305) and leave the advance loop
                 double n0 = 0, n1 = 0, nd = 0;
                 for (int i = 0; i < 3; ++i) { n0 += ps.p[0][i] * ps.p[0][i]; n1 += ps.p[1][i] * ps.p[1][i]; double d = ps.p[0][i] - ps.p[1][i]; nd += d * d; }
-                if (nd < 0.0004 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; }   // normD < 0.02 min(norms), squared
+                bool averaged = false;
+                if (nd < 0.0004 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; averaged = true; }   // normD < 0.02 min(norms), squared
                 pb.mu0 = mu0 * T; pb.mu1 = mu1 * T;                                      // stretch :293-298
                 const double lhs0 = lh0 * T, lhs1 = lh1 * T;
                 for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
                 pb.s[0] = s0; pb.s[1] = s1;
-                if (CPFIT) { pb.tgt[0] = exp(-lhs0) * s0; pb.tgt[1] = exp(-lhs1) * s1; }
+                if (!pre || averaged) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
+                if (CPFIT) { pb.tgt[0] = eh0 * s0; pb.tgt[1] = eh1 * s1; }
                 else {
-                    double pa = exp(-lhs0), pbb = exp(-lhs1);                            // ExpectedCoalTimeOnePopTmp, T = 1
+                    double pa = eh0, pbb = eh1;                                          // ExpectedCoalTimeOnePopTmp, T = 1
                     pb.tgt[0] = 1.0 / lhs0 - 1.0 / (1.0 / pa - 1.0);
                     pb.tgt[1] = 1.0 / lhs1 - 1.0 / (1.0 / pbb - 1.0);
                 }
@@ -1037,6 +1105,10 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         // ---- one residual batch at xe -------------------------------------------------
         double fn[2], Jn[2][2], w[3];
         bool finite;
+        if (it_w && sub == 0) {
+            const int i = first ? 0 : nfev;
+            if (i < MISTI_TRACE_MAX_ITER) { double* r = it_w + ((int64_t)t * MISTI_TRACE_MAX_ITER + i) * 2; r[0] = xe[0]; r[1] = xe[1]; }
+        }
         pair_batch<CPFIT, GROUP>(pb, xe, sub, dg, fn, Jn, w, finite);
         dg.evals += 1;
         STAMP(c_batch)
@@ -1093,7 +1165,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             dg.max_nfev = nfev > dg.max_nfev ? nfev : dg.max_nfev;
             for (int i = 0; i < 3; ++i) { ps.p[0][i] = gbcast<GROUP>(vk[i], 0); ps.p[1][i] = gbcast<GROUP>(vk[i], 1); }   // :313-317
             in_solve = false;
-            if (!finish_interval(x[0] / T, x[1] / T)) { active = false; break; }                              // :312, :346-348
+            // OptimizeResult.status: the termination test that fired, 1 = gtol, 0 = evaluation budget (trf.py:452-456,556-558)
+            const int code = term != 0 ? term : ((accept && fmax(fabs(g[0]), fabs(g[1])) < LSQ_GTOL) ? 1 : 0);
+            if (!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3))) { active = false; break; }   // :312, :346-348
         }
         STAMP(c_book)
     }
@@ -1352,6 +1426,7 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     Grid G;
     G.times = m.times; G.lh = m.lh; G.numT0 = m.numT; G.numT = m.numT; G.split = Lt; G.ins = -1; G.frac = 0.0;
     Model mod{&m, par, Lt, {0, 0, 0, 0}};
+    mod.bb = cb.bounds ? cb.bounds + (int64_t)cb.rep[ch] * 2 * m.n_band : nullptr;
     mod.cache();
     const double* lc_ch = cb.lc + ch * (int64_t)m.numT * 2;
     for (int i = lane; i < 2 * (m.numT + 1); i += 64) lcb[i] = ((i >> 1) < Lt) ? lc_ch[i] : 0.0;
@@ -1392,6 +1467,7 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
     Grid G;
     G.times = m.times; G.lh = m.lh; G.numT0 = m.numT; G.numT = m.numT; G.split = len; G.ins = -1; G.frac = 0.0;
     Model mod{&m, par, len, {0, 0, 0, 0}};
+    mod.bb = cb.bounds ? cb.bounds + (int64_t)cb.rep[ch] * 2 * m.n_band : nullptr;
     mod.cache();
     for (int i = lane; i < 2 * (m.numT + 1); i += 64) lcb[i] = 0.0;
     lds_fence();
@@ -1412,13 +1488,13 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
         int need = b0 > b1 ? b0 : b1;
         if (need > len) need = len;
         while (have < need && !done) {
-            done = flags[1];                       // read `done` first: the count read after it is then final
-            have = flags[0];
+            done = lds_get(flags + 1);             // read `done` first: the count read after it is then final
+            have = lds_get(flags);
             if (have >= need || done) break;
             __builtin_amdgcn_s_sleep(16);
             if (++spins > FOLLOW_SPIN_LIMIT) break;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        lds_order();                               // the rates read below were written before the count read above
         if (have < need && !done) break;           // gave up waiting: keep the prefix
         const int cut = have >= need ? len : have; // the chain ended early (failure): runs are cut where it ended
         if (t >= cut) break;
@@ -1436,7 +1512,7 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
 
 // Kernel 1 with the trunk following: 128-thread workgroups, wave 0 = the chain (one chain per wave),
 // wave 1 = its trunk.  LDS (doubles): kernel-1 staging [3 numT] | trunk xbuf [128] + rates [2 (numT+1)] |
-// hand-over rates [2 numT] | count, done flag.
+// hand-over rates [2 numT] | count, done flag [2] | per-interval constants of the chain (mu, pulse, exp(-lh T)) [6 numT].
 template <bool CPFIT>
 __global__ __launch_bounds__(128)
 void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
@@ -1444,16 +1520,23 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     double* tk = lds + 3 * (size_t)m.numT;
     double* lc_sh = tk + 128 + 2 * (size_t)(m.numT + 1);
     volatile int* flags = (volatile int*)(lc_sh + 2 * (size_t)m.numT);
-    if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;          // candidate -> chain (see correct_kernel)
-        if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
-        correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, lc_sh, flags);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (threadIdx.x == 0) flags[1] = 1;                                  // whatever way the chain ended
-    } else {
-        trunk_follow(m, n_items, params, cb, (int64_t)blockIdx.x, tk, lc_sh, flags);
+    double* pre = lc_sh + 2 * (size_t)m.numT + 2;                              // per-interval constants of the chain in progress
+    // candidate -> chain (see correct_kernel)
+    for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 128) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
+    // The grid is sized from the chain count of the previous batch of this size (a hint the host has without waiting);
+    // a workgroup walks chains blockIdx.x, blockIdx.x + gridDim.x, ... so that any grid size is correct.
+    const int64_t n_live = cb.n_chains[0];
+    for (int64_t ch = blockIdx.x; ch < n_live; ch += gridDim.x) {
+        if (threadIdx.x == 0) { lds_put(flags, 0); lds_put(flags + 1, 0); }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, ch, lds, lc_sh, flags, pre);
+            lds_order();
+            if (threadIdx.x == 0) lds_put(flags + 1, 1);                     // whatever way the chain ended
+        } else {
+            trunk_follow(m, n_items, params, cb, ch, tk, lc_sh, flags);
+        }
+        __syncthreads();                                                     // both waves are done with the hand-over area
     }
 }
 
@@ -1498,8 +1581,10 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     double* lcb = xbuf + 128;
     const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
-    int status = setup_candidate(m, split_time[cand], par, G);
+    const int32_t* bb = cb.bounds ? cb.bounds + cand * 2 * m.n_band : nullptr;
+    int status = setup_candidate(m, split_time[cand], par, G, bb);
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
+    mod.bb = bb;
     mod.cache();
     // ---- this candidate's share of its chain (+ its own tail interval after a fractional split)
     const int64_t ch = (int64_t)__builtin_amdgcn_readfirstlane((int)chain_of(cb, cand));
@@ -1517,6 +1602,17 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     }
     double* lc_o = lc_out ? lc_out + cand * (int64_t)lc_rows * 2 : nullptr;
     double* pr_o = pr_out ? pr_out + cand * (int64_t)(m.numT + 2) * 6 : nullptr;
+    int32_t* sv_o = cb.cand_solver ? cb.cand_solver + cand * (int64_t)lc_rows : nullptr;
+    if (sv_o) {
+        // solver trace of this candidate: its share of the chain (+ the shortened interval of a fractional split);
+        // the post-split intervals are added below
+        for (int i = lane; i < lc_rows; i += 64) {
+            int32_t wd = 0;
+            if (i < nfull && i < have) wd = cb.solver[ch * (int64_t)m.numT + i];
+            else if (i == nfull && G.ins >= 0 && have > nfull) wd = cb.tail_solver[cand];
+            sv_o[i] = wd;
+        }
+    }
     if (pr_o) {
         // .Pr trace (MigrationInference.py:309,350): rows 0..split from the chain (+ tail); last row = work counters
         const int rows = (status == MISTI_OK) ? G.split + 1 : (have > nfull ? nfull + 1 : (have > 0 ? have : (status == MISTI_OK ? 1 : 0)));
@@ -1588,11 +1684,13 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
             if (t < last) {
                 double T = G.T(t);
                 double lam = 1.0;
+                int32_t word = 0;
                 if (T != 0) {
                     double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
                     if (CPFIT) {
                         double pnc = (exp(-T * lh0) + exp(delta - T * lh1)) / (1.0 + ed);   // :366
                         lam = -log(pnc) / T;
+                        word = solver_word(0, 0, 1);
                     } else {
                         // FitSinglePop :88-92 with P0 = [[exp(nc0),0,0],[exp(nc1),0,0]] (:361)
                         double pa = exp(nc0), pb = exp(nc1);
@@ -1600,15 +1698,17 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                         double Te = w0 * ect_one_pop(lh0, T) + w1 * ect_one_pop(lh1, T);
                         double x[1] = {w0 * lh0 + w1 * lh1};
                         auto resid = [&](const double l[1], double f[1]) { f[0] = ect_one_pop(l[0], T) - Te; };
-                        trf_bounded<1>(resid, x, 0.01 * fmin(lh0, lh1));
+                        word = trf_bounded<1>(resid, x, 0.01 * fmin(lh0, lh1));
                         lam = x[0];
                     }
                 }
                 lcb[2 * t] = lam; lcb[2 * t + 1] = lam;
+                if (sv_o) sv_o[t] = word;
             } else if (t == last) {
                 double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
                 double lam = (1.0 + ed) / (1.0 / lh0 + ed / lh1);                            // :372-376
                 lcb[2 * t] = lam; lcb[2 * t + 1] = lam;
+                if (sv_o) sv_o[t] = solver_word(0, 0, 1);
             }
         }
         lds_fence();
@@ -1751,12 +1851,16 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // (read-only input), so a collision costs a probe, never correctness.  Chain ids depend on the
 // order of arrival - they only name buffers; no result depends on them.
 __global__ __launch_bounds__(256)
-void discover_kernel(int64_t n, int P, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb) {
+void discover_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
+        // the key: the parameter bits and, with per-candidate band bounds, the (start, end) pairs as given (end == -1
+        // stays symbolic: members of a chain may differ in their split, never in where a band starts or ends)
         uint64_t h = 0x243f6a8885a308d3ull;
         const double* a = params + i * P;
+        const int32_t* ab = cb.bounds ? cb.bounds + i * NB2 : nullptr;
         for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
+        if (ab) for (int k = 0; k < NB2; ++k) h = mix64(h ^ (uint64_t)(uint32_t)ab[k]);
         uint32_t s = (uint32_t)(h >> 20) & cb.tmask;
         for (;;) {
             const int prev = atomicCAS(&cb.table[s], 0, (int)i + 1);
@@ -1770,6 +1874,7 @@ void discover_kernel(int64_t n, int P, const double* __restrict__ params, const 
             const double* b = params + (int64_t)(prev - 1) * P;
             bool same = true;
             for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) same = false;
+            if (ab) { const int32_t* bbp = cb.bounds + (int64_t)(prev - 1) * NB2; for (int k = 0; k < NB2; ++k) if (ab[k] != bbp[k]) same = false; }
             if (same) break;
             s = (s + 1) & cb.tmask;
         }
@@ -1801,9 +1906,9 @@ uint32_t chain_table_size(int64_t n_cand) {
     return t;
 }
 
-hipError_t launch_chain_discovery(int64_t n, int P, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream) {
+hipError_t launch_chain_discovery(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(discover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, P, params, split, numT, cb);
+    hipLaunchKernelGGL(discover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, P, 2 * n_band, params, split, numT, cb);
     return hipGetLastError();
 }
 
@@ -1960,14 +2065,22 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 
 // the chains (the number of live chains is read on the device: slots beyond it exit at once)
 // cpw: chains per wavefront, chosen by the caller from the expected number of chains
+// est_chains: chains of the previous batch of this size on the context, or < 0 when unknown
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, hipStream_t stream) {
+                          int cpw, bool follow, int64_t est_chains, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     if (follow) {
-        const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT) * sizeof(double) + 4 * sizeof(int);
-        if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
-        else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)n_cand), dim3(128), lds, stream, m, n_cand, cb, split, params);
+        const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT + 2 + 6 * (size_t)m.numT) * sizeof(double);
+        // one workgroup per chain expected (any grid is correct: workgroups stride over the chains); not n_cand
+        // workgroups of which all but n_chains leave at once (4 096 x 128 threads through the dispatcher for 64 chains)
+        int64_t blocks = (est_chains > 0 && est_chains < n_cand) ? est_chains : n_cand;
+        // the hint may be stale (same batch size, other parameters): never fewer than 1 024 workgroups for a larger batch, so
+        // that a wrong guess costs at most a few chains in sequence per workgroup (idle workgroups leave at once)
+        const int64_t floor_blocks = n_cand < 1024 ? n_cand : 1024;
+        if (blocks < floor_blocks) blocks = floor_blocks;
+        if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
+        else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
         return hipGetLastError();
     }
     MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, stream)

@@ -90,6 +90,7 @@ class Engine:
         self.unfolded = bool(unfolded)
         bands = list(bands)
         pulses = list(pulses)
+        self.n_band = len(bands)
         b_arr = (_lib.Band * max(1, len(bands)))()
         for i, (pop, start, end, value, param) in enumerate(bands):
             b_arr[i] = _lib.Band(int(pop), int(start), int(end), int(param), float(value))
@@ -123,8 +124,11 @@ class Engine:
         self.close()
 
     # -- host-buffer evaluation ----------------------------------------------
-    def evaluate(self, split_time, params=None, jsfs=None, want_lc=False, want_pr=False):
-        """``misti_eval_batch``: NumPy in, NumPy out (copies over PCIe)."""
+    def evaluate(self, split_time, params=None, jsfs=None, want_lc=False, want_pr=False, band_bounds=None):
+        """``misti_eval_batch``: NumPy in, NumPy out (copies over PCIe).
+
+        ``band_bounds`` ([n][n_band][2] ints, optional): per-candidate (start, end) of every band, replacing the
+        model's (``end == -1``: the candidate's split index) - the README's ``::: st ... ::: mc ...`` sweep in one call."""
         split = _f64(np.atleast_1d(split_time))
         n = split.shape[0]
         P = self.n_param
@@ -139,7 +143,10 @@ class Engine:
         lc = np.empty((n, self.numT + 1, 2)) if want_lc else None
         pr = np.empty((n, self.numT + 2, 6)) if want_pr else None
         ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
-        _lib.check(self._lib.misti_eval_batch(self._ctx, n, ptr(split), ptr(par), R, ptr(rows), ptr(llk), ptr(jafs),
+        bb = None
+        if band_bounds is not None and self.n_band:
+            bb = np.ascontiguousarray(band_bounds, dtype=np.int32).reshape(n, self.n_band, 2)
+        _lib.check(self._lib.misti_eval_batch(self._ctx, n, ptr(split), ptr(par), ptr(bb), R, ptr(rows), ptr(llk), ptr(jafs),
                                               ptr(lc), ptr(pr), ptr(status)))
         return BatchResult(llk, jafs, status, lc, pr, self.last_diag(n) if n else np.zeros(0))
 
@@ -177,10 +184,10 @@ class Engine:
         _lib.check(self._lib.misti_get_stream(self._ctx, C.byref(h)))
         return h.value or 0
 
-    def evaluate_dev(self, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0):
+    def evaluate_dev(self, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0, d_bounds=0):
         """``misti_eval_batch_dev``: raw device addresses (ints); asynchronous."""
         v = lambda p: C.c_void_p(int(p)) if p else None
-        _lib.check(self._lib.misti_eval_batch_dev(self._ctx, int(n_cand), v(d_split), v(d_params), int(n_rep), v(d_jsfs),
+        _lib.check(self._lib.misti_eval_batch_dev(self._ctx, int(n_cand), v(d_split), v(d_params), v(d_bounds), int(n_rep), v(d_jsfs),
                                                   v(d_llk), v(d_jafs), v(d_lc), v(d_pr), v(d_status)))
 
     def llk_dev(self, n_cand, d_jafs, d_status, n_rep, d_jsfs, d_llk):
@@ -194,6 +201,26 @@ class Engine:
 
     def sync(self):
         _lib.check(self._lib.misti_sync(self._ctx))
+
+    def enable_solver_trace(self, on=True):
+        """Record, for the following batches, SciPy-comparable solver statistics per candidate and interval
+        (``misti_enable_solver_trace``; see ``solver_trace``)."""
+        _lib.check(self._lib.misti_enable_solver_trace(self._ctx, 1 if on else 0))
+
+    def solver_trace(self, n_cand, cand=None):
+        """Solver trace of the last batch: dict of ``nfev``, ``status``, ``kind`` arrays ``[n_cand][numT+1]``
+        (kind 0 none, 1 closed form, 2 bounded TRF, 3 unbounded TRF; status = SciPy's termination code) and, with
+        ``cand`` given (batches of at most 64 candidates), ``iterates [numT][200][2]``: the trial points of the
+        unbounded solves of that candidate's chain (NaN beyond nfev)."""
+        n = int(n_cand)
+        words = np.empty((n, self.numT + 1), dtype=np.int32)
+        its = np.empty((self.numT, _lib.TRACE_MAX_ITER, 2)) if cand is not None else None
+        _lib.check(self._lib.misti_last_solver_trace(self._ctx, n, words.ctypes.data_as(C.c_void_p), int(cand) if cand is not None else 0,
+                                                     its.ctypes.data_as(C.c_void_p) if its is not None else None))
+        out = {"nfev": words & 0xffff, "status": (words >> 16) & 15, "kind": (words >> 20) & 15}
+        if its is not None:
+            out["iterates"] = its
+        return out
 
     def enable_timing(self, on=True):
         _lib.check(self._lib.misti_enable_timing(self._ctx, 1 if on else 0))

@@ -31,10 +31,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, "/root/reference")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import migrationIO                     # noqa: E402  (reference)
 import MigrationInference as MI        # noqa: E402  (reference)
+import CorrectLambda as CL              # noqa: E402  (reference)
+from scipy import optimize             # noqa: E402
 from misti_amd import synth            # noqa: E402
+import parity                          # noqa: E402  (tests/parity.py: the perturbation family and the contract's constants)
 
 
 def run_reference(times, lambdas, sfs, split, mi, pu, kw, params):
@@ -57,45 +61,136 @@ def run_reference(times, lambdas, sfs, split, mi, pu, kw, params):
     return rec
 
 
-PERTURB = 2.0 ** -48      # relative input perturbation used to measure the reference's own conditioning
+PERTURB = parity.PERTURB      # relative input perturbation used to measure the reference's own conditioning
 
 
-def sensitivity(times, lambdas, sfs, split, mi, pu, kw, params, llh):
-    """Amplification of a 2^-48 relative perturbation of the inputs into the
-    reference's log-likelihood: max over three perturbations of
-    |llh' - llh| / |llh| / 2^-48  (None where a perturbed run fails).  The
-    lambda-correction solves stop on SciPy's gtol test after a few finite-difference
-    trust-region steps; where the residual is flat (the pair has all but coalesced
-    inside the interval) the stopping point is decided by rounding noise and the
-    reference's own output is not determined to 1e-9."""
-    worst = 0.0
-    for kind in range(3):
-        if kind == 0:
-            L = [[a * (1 + PERTURB), b * (1 - PERTURB)] for a, b in lambdas]
-            T = list(times)
-        elif kind == 1:
-            L = [[a * (1 - PERTURB), b * (1 + PERTURB)] for a, b in lambdas]
-            T = list(times)
-        else:
-            L = [list(x) for x in lambdas]
-            T = [t * (1 + PERTURB) for t in times]
-        r = run_reference(T, L, sfs, split, mi, pu, kw, params)
-        if r["llh"] is None:
-            return None
-        worst = max(worst, abs(r["llh"] - llh) / abs(llh) / PERTURB)
-    return worst
+def perturbation_study(times, lambdas, sfs, split, mi, pu, kw, params, llh, kinds):
+    """The reference's own indeterminacy for this case: it is re-run on inputs perturbed by 2^-48
+    (relative; `parity.perturbed`, kinds 0..kinds-1).  The lambda-correction solves stop on SciPy's
+    tests after a few finite-difference trust-region steps; where the residual is flat (the pair has
+    all but coalesced inside the interval) the stopping point is decided by rounding noise and the
+    reference's own output is not determined to 1e-9.  Returns
+      sens       max over kinds 0-2 of |llh' - llh| / |llh| / 2^-48 (None where one of them fails) - round 1's figure
+      spread     max over all kinds run of |llh' - llh| / |llh| (finite perturbed runs)
+      pert_fail  number of perturbed runs that ended in "correction failed"
+      pert_llh   the perturbed values themselves (None = failed)."""
+    vals = []
+    for kind in range(kinds):
+        T, L = parity.perturbed(times, lambdas, kind)
+        vals.append(run_reference(T, L, sfs, split, mi, pu, kw, params)["llh"])
+    base = [v for v in vals[:3]]
+    sens = None if any(v is None for v in base) else max(abs(v - llh) / abs(llh) / PERTURB for v in base)
+    fin = [v for v in vals if v is not None]
+    spread = max(abs(v - llh) / abs(llh) for v in fin) if fin else None
+    return sens, spread, sum(1 for v in vals if v is None), vals
 
 
 def case(name, times, lambdas, sfs, split, mi=(), pu=(), params=(), **kw):
     t0 = time.time()
     rec = run_reference(times, lambdas, sfs, split, mi, pu, kw, params)
-    if rec["llh"] is not None and name != "tmp":
-        rec["sens"] = sensitivity(times, lambdas, sfs, split, mi, pu, kw, params, rec["llh"])
+    if name != "tmp":
+        if rec["llh"] is not None:
+            sens, spread, nfail, vals = perturbation_study(times, lambdas, sfs, split, mi, pu, kw, params, rec["llh"], parity.N_KINDS_BASE)
+            if sens is None or sens >= parity.SENS_DETERMINED:      # reference-indeterminate: sample its spread more densely
+                _, spread, nfail, vals = perturbation_study(times, lambdas, sfs, split, mi, pu, kw, params, rec["llh"], parity.N_KINDS_DEEP)
+            rec["sens"], rec["spread"], rec["pert_fail"], rec["pert_llh"] = sens, spread, nfail, vals
+        else:
+            # a failing case: does the reference flip to a value under the same perturbations?
+            vals = [run_reference(*parity.perturbed(times, lambdas, k), sfs, split, mi, pu, kw, params)["llh"] for k in range(parity.N_KINDS_BASE)]
+            rec["pert_finite"] = sum(1 for v in vals if v is not None)
     return {"name": name,
             "in": {"times": list(times), "lambdas": [list(x) for x in lambdas], "sfs": list(sfs),
                    "split": split, "mi": [list(x) for x in mi], "pu": [list(x) for x in pu],
                    "kw": kw, "params": list(params)},
             "out": rec, "ref_seconds": round(time.time() - t0, 3)}
+
+
+# ---- solver traces ---------------------------------------------------------------------------
+class SolverTrace:
+    """Log every scipy.optimize.least_squares call the reference makes (CorrectLambda.py:85,260,303,305):
+    which interval, the start, the result, nfev, status and the TRIAL POINTS - the evaluation points that
+    are not finite-difference points of the 2-point Jacobian (after each accepted point SciPy evaluates
+    x + h_i e_i for i = 0..n-1, h_i = sqrt(eps) max(1, |x_i|) sign(x_i), flipped at a bound)."""
+
+    SITES = {"LambdaSystem": "two_pop_ect", "LambdaSystem1": "two_pop_cp", "LambdaSystemNoMigration": "no_migration", "<lambda>": "single_pop"}
+
+    def __enter__(self):
+        self.solves = []
+        self.seq = -1
+        self.orig_ls = optimize.least_squares
+        self.orig_si = CL.CorrectLambda.SetInterval
+        tracer = self
+
+        def set_interval(obj, lh, T, P0):
+            tracer.seq += 1
+            return tracer.orig_si(obj, lh, T, P0)
+
+        def least_squares(fun, x0, *a, **kw):
+            calls = []
+
+            def logged(x, *aa, **kk):
+                calls.append([float(v) for v in numpy.atleast_1d(x)])
+                return fun(x, *aa, **kk)
+            res = tracer.orig_ls(logged, x0, *a, **kw)
+            n = len(calls[0])
+            trials, i = [], 0
+            while i < len(calls):
+                xt = calls[i]
+                trials.append(xt)
+                fd = calls[i + 1:i + 1 + n]
+                is_fd = len(fd) == n
+                for j, xf in enumerate(fd):
+                    h = 1.4901161193847656e-08 * max(1.0, abs(xt[j]))
+                    for k in range(n):
+                        d = abs(xf[k] - xt[k])
+                        if (k == j and not (0.5 * h <= d <= 2.0 * h)) or (k != j and d != 0.0):
+                            is_fd = False
+                i += 1 + (n if is_fd else 0)
+            assert len(trials) == res.nfev, (len(trials), res.nfev)
+            tracer.solves.append({"seq": tracer.seq, "site": tracer.SITES.get(getattr(fun, "__name__", "?"), "?"),
+                                  "x0": [float(v) for v in numpy.atleast_1d(x0)], "x": [float(v) for v in res.x],
+                                  "nfev": int(res.nfev), "status": int(res.status), "optimality": float(res.optimality),
+                                  "trials": trials})
+            return res
+        optimize.least_squares = least_squares
+        CL.CorrectLambda.SetInterval = set_interval
+        return self
+
+    def __exit__(self, *exc):
+        optimize.least_squares = self.orig_ls
+        CL.CorrectLambda.SetInterval = self.orig_si
+
+
+def traced(c):
+    """Re-run golden case `c` under SolverTrace; the traced run must reproduce the recorded llh bit for bit."""
+    i = c["in"]
+    with SolverTrace() as tr:
+        rec = run_reference(i["times"], i["lambdas"], i["sfs"], i["split"], i["mi"], i["pu"], i["kw"], i["params"])
+    assert rec["llh"] == c["out"]["llh"], (c["name"], rec["llh"], c["out"]["llh"])
+    # interval index of every solve: the two-population intervals call SetInterval once each (t = seq); after the
+    # split only the default fit does, skipping zero-length intervals (MigrationInference.py:355-362)
+    splitT, numT = rec["splitT"], rec["numT"]
+    times = list(i["times"])
+    frac = i["split"] % 1
+    if frac != 0.0:                                   # the grid the reference works on (:89-99)
+        s0 = int(i["split"])
+        t1 = frac * times[s0]
+        times[s0:s0 + 1] = [t1, times[s0] - t1]
+    post = [t for t in range(splitT, numT - 1) if times[t] != 0]
+    n_two = splitT if not i["kw"].get("trueEPS") else 0
+    for sv in tr.solves:
+        sv["t"] = sv["seq"] if sv["seq"] < n_two else post[sv["seq"] - n_two]
+    return {"name": c["name"], "numT": numT, "splitT": splitT, "solves": tr.solves}
+
+
+def wants_trace(c):
+    """Every reference-indeterminate golden, every default-fit case with a band or a pulse, and a few determined controls."""
+    o, kw, i = c["out"], c["in"]["kw"], c["in"]
+    if o["llh"] is None:
+        return False
+    indet = o.get("sens") is None or o["sens"] >= parity.SENS_DETERMINED
+    default_mig = not kw.get("cpfit") and not kw.get("trueEPS") and (len(i["mi"]) > 0 or len(i["pu"]) > 0)
+    return indet or default_mig or c["name"] in ("A1", "A3", "A7", "B6", "c1_n32_default", "c2_n128_st60_r0.2", "c4_n128_default_st44.5")
 
 
 def anchors():
@@ -266,6 +361,114 @@ def ms_cases():
     return out
 
 
+def sweep_cases():
+    """The reference's own recommended sweep (README.md:110-115): four fixed bands whose rates change at interval
+    {mc}, `-mi 1 0 {mc} a 0 -mi 2 0 {mc} b 0 -mi 1 {mc} {st} c 0 -mi 2 {mc} {st} d 0 -uf`, over st x mc x rates,
+    one reference run per grid point.  The HIP path evaluates the whole grid in ONE call with per-candidate band
+    bounds (misti_eval_batch's band_bounds).  numT = 32; the README's default fit and --cpfit."""
+    inp = synth.psmc_pair(16, 17)
+    st0, mc0 = 20, 9
+    true_mi = [[1, 0, mc0, 0.3, 0], [2, 0, mc0, 0.1, 0], [1, mc0, st0, 0.05, 0], [2, mc0, st0, 0.4, 0]]
+    t32, lh32, _ = synth.self_consistent(inp, st0, true_mi)
+    truth = case("tmp", t32, lh32, [1] * 8, st0, true_mi, trueEPS=True, cpfit=True, unfolded=True)
+    sfs = synth.counts_from_spectrum(truth["out"]["JAFS"])
+    out = []
+    for cp in (True, False):
+        for st in (19, 20, 21, 22.5):
+            end = int(st) + (1 if st % 1 else 0)
+            for mc in (8, 9, 10, 11):
+                for ri, rates in enumerate(([0.3, 0.1, 0.05, 0.4], [0.02, 0.5, 0.25, 0.0])):
+                    mi = [[1, 0, mc, rates[0], 0], [2, 0, mc, rates[1], 0], [1, mc, end, rates[2], 0], [2, mc, end, rates[3], 0]]
+                    kw = dict(smooth=True, unfolded=True)
+                    if cp:
+                        kw["cpfit"] = True
+                    c = case("sw_%s_st%g_mc%d_r%d" % ("cp" if cp else "df", st, mc, ri), t32, lh32, sfs, st, mi, **kw)
+                    c["sweep"] = {"st": st, "mc": mc, "rates": rates}
+                    out.append(c)
+    return out
+
+
+def raw(v):
+    """JSON-able copy that keeps Python ints as ints and turns NumPy scalars into Python floats."""
+    if isinstance(v, (list, tuple)) or hasattr(v, "tolist") and getattr(v, "ndim", 0) > 0:
+        return [raw(x) for x in v]
+    if isinstance(v, (bool, int)):
+        return v
+    return float(v)
+
+
+def host_fixtures(tmp):
+    """Reference outputs that pin the host-side pieces of the path (f2): the `#MiSTI2 ver 0.4` writer
+    (migrationIO.OutputMigration :346-375), the bootstrap resampler under a fixed seed (BootstrapJAFS :506-524 as
+    utils/generateJSFS_bs.py:39-48 drives it) and MiSTI.py's machine-read result line (:240) with its -o file."""
+    import subprocess
+    import types
+    T = [0.01, 0.02, 0.04, 0.08, 0.16, 0.32, 0.64]
+    L = [[1, 2], [1, 2], [0.8, 1.5], [0.8, 1.5], [1.2, 1.0], [1.2, 1.0], [0.9, 0.9], [0.7, 0.7]]
+    S = [100000, 900, 250, 1000, 600, 400, 260, 410]
+    two = [[1, 1, 5, 0.3, 1], [2, 1, 5, 0.1, 1]]
+    writer = []
+    for name, split, mi, pu, params, kw in [("A3", 5, two, [], [0.3, 0.1], dict(smooth=True, cpfit=True, unfolded=True)),
+                                             ("A6", 5, [[1, 2, 5, 0.3, 0]], [], [], dict(smooth=True, cpfit=True, sampleDate=2)),
+                                             ("A7", 4.5, [], [], [], dict(smooth=True, cpfit=True))]:
+        sink = io.StringIO()
+        with contextlib.redirect_stdout(sink):
+            m = MI.MigrationInference(list(T), [list(x) for x in L], list(S), split, [list(x) for x in mi], [list(x) for x in pu],
+                                      thrh=[0.0521, 0.0104], **kw)
+            m.JAFSLikelihood(list(params))
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            migrationIO.OutputMigration("", list(params), m, 1234.5, 0.75)
+        text = out.getvalue()
+        text = text[text.index("#MiSTI2"):]
+        writer.append({"name": name, "in": {"times": T, "lambdas": L, "sfs": S, "split": split, "mi": mi, "pu": pu, "params": params,
+                                            "kw": kw, "thrh": [0.0521, 0.0104], "scaleTime": 1234.5, "scaleEPS": 0.75},
+                       # attribute values as the reference holds them (Python ints stay ints: str(0) != str(0.0) in the text)
+                       "model": {"times": raw(m.times), "splitT": m.splitT, "sampleDate": m.sampleDate, "thrh": raw(m.thrh),
+                                 "JAFS": raw(m.JAFS), "dataJAFS": raw(m.dataJAFS), "lc": raw(m.lc), "lh": raw(m.lh),
+                                 "mi": raw(m.mi), "Pr": raw(m.Pr), "llh": raw(m.llh)},
+                       "text": text})
+    # bootstrap resampling: the reference draws with the module-level `random` (seeded here; MiSTI.py seeds from the clock)
+    import random as pyrandom
+    rows = synth.chunk_rows([1000000, 52000, 31000, 47000, 28000, 9000, 14000, 8000], 20)
+    boot = []
+    for seed in (0, 1, 12345):
+        for normalize in (False, True):
+            pyrandom.seed(seed)
+            draws = [migrationIO.BootstrapJAFS(types.SimpleNamespace(jafs=[list(r) for r in rows]), normalize) for _ in range(3)]
+            boot.append({"seed": seed, "normalize": normalize, "draws": [[float(v) for v in d] for d in draws]})
+    pyrandom.seed(5)
+    table = [[sum(r[i] for r in rows) for i in range(8)]] + [migrationIO.BootstrapJAFS(types.SimpleNamespace(jafs=[list(r) for r in rows]), False) for _ in range(4)]
+    # MiSTI.py end to end, one OS process per run (its module state - Units, the JAFS reader's mutable default - is global)
+    f1, f2, fj = (os.path.join(tmp, n) for n in ("g1.psmc", "g2.psmc", "data.sfs"))
+    t1, t2 = synth.psmc_text(16, 1, synth.THETA_1), synth.psmc_text(17, 2, synth.THETA_2)
+    open(f1, "w").write(t1)
+    open(f2, "w").write(t2)
+    d = migrationIO.ReadPSMC(f1, f2, 0)
+    truth = case("tmp", d.times, d.lambdas, [1] * 8, 20, trueEPS=True, cpfit=True, unfolded=True)
+    from misti_amd import io as mio
+    jtext = mio.format_jsfs(synth.chunk_rows(synth.counts_from_spectrum(truth["out"]["JAFS"], 200000), 5))
+    open(fj, "w").write(jtext)
+    runs = []
+    for args in (["20", "--cpfit", "-bs", "0", "-o", "res.mi"], ["20"], ["19.5", "--cpfit", "-uf", "-bs", "2"],
+                 ["20", "-mi", "1", "2", "20", "0.1", "0", "--cpfit", "-bs", "0", "-o", "res.mi"]):
+        argv = ["MiSTI.py", "g1.psmc", "g2.psmc", "data.sfs"] + args + ["-wd", tmp]
+        code = ("import numpy, sys, runpy; numpy.mat = numpy.asmatrix; sys.argv = %r; sys.path.insert(0, '/root/reference'); "
+                "runpy.run_path('/root/reference/MiSTI.py', run_name='__main__')" % (argv,))
+        res = os.path.join(tmp, "res.mi")
+        if os.path.exists(res):
+            os.remove(res)
+        r = subprocess.run([sys.executable, "-c", code], cwd="/root/reference", capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("bs_id =")]
+        assert len(line) == 1, r.stdout[-2000:]
+        runs.append({"args": args, "result_line": line[0], "stdout": r.stdout.replace(tmp, "<wd>"),
+                     "out_file": open(res).read() if os.path.exists(res) else None})
+    return {"writer": writer, "bootstrap": {"rows": rows, "draws": boot, "table_seed5": [[float(v) for v in r] for r in table]},
+            "cli": {"psmc1": t1, "psmc2": t2, "jsfs": jtext, "units": open("/root/reference/setunits.txt").read(), "runs": runs}}
+
+
 def dedupe(cases):
     """Store each (times, lambdas) grid once; cases refer to it by key."""
     grids = {}
@@ -287,15 +490,22 @@ def dedupe(cases):
 
 def main():
     t0 = time.time()
+    if "--host-only" in sys.argv:
+        with tempfile.TemporaryDirectory() as tmp:
+            host = host_fixtures(tmp)
+        json.dump({"generator": "tests/golden/make_golden.py", **host}, open(os.path.join(HERE, "golden_host.json"), "w"))
+        return
     with tempfile.TemporaryDirectory() as tmp:
         readers = reader_dumps(tmp)
     json.dump({"generator": "tests/golden/make_golden.py", "cases": readers},
               open(os.path.join(HERE, "golden_readers.json"), "w"))
     a = anchors()
+    traces = [traced(c) for c in a if wants_trace(c)]
     json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6",
                "grids": dedupe(a), "cases": a},
               open(os.path.join(HERE, "golden_small.json"), "w"))
     s = synthetic_cases()
+    traces += [traced(c) for c in s if wants_trace(c)]
     for c in s:                        # the pair-state trace is pinned by the small cases
         c["out"].pop("Pr", None)
     json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6",
@@ -304,8 +514,21 @@ def main():
     ms = ms_cases()
     json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6", "cases": ms},
               open(os.path.join(HERE, "golden_ms.json"), "w"))
-    n_inf = sum(1 for x in a + s if x["out"]["llh"] is None)
-    print("wrote %d small + %d synthetic cases (%d -inf) in %.1f s" % (len(a), len(s), n_inf, time.time() - t0))
+    sw = sweep_cases()
+    for c in sw:
+        c["out"].pop("Pr", None)
+    sw_traces = [traced(c) for c in sw if c["name"] in ("sw_df_st20_mc9_r0", "sw_cp_st22.5_mc10_r1")]
+    json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "numpy": "2.2.6", "grids": dedupe(sw), "cases": sw},
+              open(os.path.join(HERE, "golden_sweep.json"), "w"))
+    with tempfile.TemporaryDirectory() as tmp:
+        host = host_fixtures(tmp)
+    json.dump({"generator": "tests/golden/make_golden.py", **host}, open(os.path.join(HERE, "golden_host.json"), "w"))
+    import gzip
+    with gzip.open(os.path.join(HERE, "golden_traces.json.gz"), "wt") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "scipy": "1.15.3", "cases": traces + sw_traces}, f)
+    n_inf = sum(1 for x in a + s + sw if x["out"]["llh"] is None)
+    print("wrote %d small + %d synthetic + %d sweep cases (%d -inf), %d solver traces in %.1f s"
+          % (len(a), len(s), len(sw), n_inf, len(traces) + len(sw_traces), time.time() - t0))
 
 
 if __name__ == "__main__":

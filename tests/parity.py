@@ -34,26 +34,66 @@ def llk_tol(ref_llk, row, jafs, unfolded):
     return LLK_RTOL * abs(ref_llk) + FLOOR_ULPS * EPS * llk_summand_scale(row, jafs, unfolded)
 
 
-# Conditioning of the reference itself.  make_golden.py records `sens`: the factor by which
-# a 2^-48 relative perturbation of the inputs is amplified in the reference's llh.  Normal
-# candidates have sens ~1e3 (cancellation against llh_const); candidates whose lambda-correction
-# ran into a flat residual (runaway corrected rate) have sens 1e6..1e10: there the reference's
-# stopping point - and even whether it reports "correction failed" - is decided by rounding
-# noise, so no independent implementation (nor the reference on another BLAS) reproduces it to
-# 1e-9.  Parity at LLK_RTOL is asserted for determined candidates; for the others only
-# agreement within the measured indeterminacy (or a failure status) is required.
+# ---- the contract -----------------------------------------------------------------------------
+# Per candidate, the HIP path must satisfy ONE of
+#   (1)  |llk - ref| <= 1e-9 |ref| + rounding floor of the reference's own last line     (llk_tol)
+#   (2)  |llk - ref| <= SELF_FACTOR x the reference's own measured indeterminacy for THAT candidate
+# where the indeterminacy is `spread`: the largest relative change of the reference's llh under
+# 2^-48 relative perturbations of its inputs (make_golden.py / tools/self_perturbation.py run the
+# reference - or, for the random campaign, the oracle that reproduces it - on the perturbed inputs
+# `perturbed(times, lambdas, kind)` below).  Background: the lambda-correction's corrected rates
+# are defined by where SciPy's trust-region iteration stops; its finite-difference Jacobian
+# (h = 1.5e-8) amplifies rounding noise of the residual by ~1e8, so wherever the residual is flat in
+# one rate (pair all but coalesced: "runaway" rate; default fit with migration) the reference moves
+# by 1e-8..1e-1 under a last-bits perturbation, and no implementation with different rounding - the
+# reference on another BLAS included - can reproduce it more closely than that.
+# A failure status against a finite reference value (or the reverse) is accepted only where the
+# reference itself flips between a value and "correction failed" under those perturbations.
 PERTURB = 2.0 ** -48
-SENS_DETERMINED = 3e4          # sens * 2^-48 < 1e-10
+SELF_FACTOR = 10.0
+N_KINDS_BASE = 3          # perturbations every finite golden case has
+N_KINDS_DEEP = 9          # ... and every indeterminate one (sens >= SENS_DETERMINED)
+SENS_DETERMINED = 3e4     # sens * 2^-48 < 1e-10: (1) is expected to hold
+
+
+def perturbed(times, lambdas, kind):
+    """Inputs with a 2^-48 relative perturbation.  Kinds 0-2: genome-1 rates up / genome-2 down, the
+    reverse, interval lengths up (the three of round 1); kind >= 3: independent random signs on every
+    rate and every interval length, seeded by the kind."""
+    import random as _random
+    T = [float(t) for t in times]
+    L = [[float(a), float(b)] for a, b in lambdas]
+    if kind == 0:
+        L = [[a * (1 + PERTURB), b * (1 - PERTURB)] for a, b in L]
+    elif kind == 1:
+        L = [[a * (1 - PERTURB), b * (1 + PERTURB)] for a, b in L]
+    elif kind == 2:
+        T = [t * (1 + PERTURB) for t in T]
+    else:
+        rng = _random.Random(1000 + kind)
+        sg = lambda: 1 + PERTURB * rng.choice((-1, 1))
+        L = [[a * sg(), b * sg()] for a, b in L]
+        T = [t * sg() for t in T]
+    return T, L
 
 
 def determined(out):
     return out.get("sens") is not None and out["sens"] < SENS_DETERMINED
 
 
-def loose_rtol(out):
+def spread_of(out):
+    """The reference's measured relative indeterminacy of this golden case (None: unknown / a perturbed run failed)."""
+    if out.get("spread") is not None:
+        return out["spread"]
     k = out.get("sens")
-    # three perturbations sample the (discrete, flip-driven) indeterminacy only coarsely: allow 1000 x
-    return 1e-2 if k is None else min(1e-2, max(LLK_RTOL, 1000.0 * k * PERTURB))
+    return None if k is None else k * PERTURB
+
+
+def llk_bound(ref_llk, row, jafs, unfolded, spread):
+    """Largest |llk - ref| the contract allows, and which clause grants it ('1e-9' or 'self')."""
+    tight = llk_tol(ref_llk, row, jafs, unfolded)
+    loose = SELF_FACTOR * spread * abs(ref_llk) if spread is not None else 0.0
+    return (tight, "1e-9") if tight >= loose else (loose, "self")
 
 
 def engine_args(case_in):

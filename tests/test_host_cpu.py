@@ -58,6 +58,32 @@ def test_jsfs_roundtrip_and_bootstrap():
         mio.read_jsfs(io.StringIO("#MiSTI_JSFS version 1.0\ntotal\n1\t2\n"))
 
 
+def host_fixtures():
+    return json.load(open(os.path.join(GOLDEN, "golden_host.json")))
+
+
+def test_result_writer_reproduces_the_reference_text():
+    """io.format_migration on the reference's own attribute values gives the reference's `#MiSTI2 ver 0.4` text
+    byte for byte (migrationIO.OutputMigration :346-375; A3 optimised bands + unfolded, A6 ancient sample, A7
+    fractional split)."""
+    import types
+    for c in host_fixtures()["writer"]:
+        m = types.SimpleNamespace(**{k: c["model"][k] for k in ("times", "splitT", "sampleDate", "thrh", "JAFS", "dataJAFS", "lc", "lh", "mi", "Pr")})
+        text = mio.format_migration(m, c["model"]["llh"], c["in"]["scaleTime"], c["in"]["scaleEPS"])
+        assert text + "\n" == c["text"], c["name"]            # the reference prints the block (print adds the final newline)
+
+
+def test_bootstrap_resampling_reproduces_the_reference_sequence():
+    """BootstrapJAFS under random.seed(k) (migrationIO.py:506-524) and the table of utils/generateJSFS_bs.py:39-48."""
+    import random
+    b = host_fixtures()["bootstrap"]
+    for d in b["draws"]:
+        rng = random.Random(d["seed"])
+        got = [mio.bootstrap_jsfs(b["rows"], rng, d["normalize"]) for _ in range(3)]
+        assert got == d["draws"], (d["seed"], d["normalize"])
+    assert mio.bootstrap_table(b["rows"], 4, random.Random(5)) == b["table_seed5"]
+
+
 def test_units_file(tmp_path):
     f = tmp_path / "u.txt"
     f.write_text("mutRate=2.5e-8\nbinsize=100\nN0=5000\ngenTime=29\njunk\n")
@@ -74,7 +100,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.misti_abi_version() == 1
+    assert lib.misti_abi_version() == 2 == _lib.ABI_VERSION
+    assert "#define MISTI_ABI_VERSION 2" in hdr
 
 
 def test_tables_match_oracle_structure():

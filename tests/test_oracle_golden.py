@@ -11,6 +11,7 @@ from oracle.misti_oracle import OracleModel, TWO_POP, ONE_POP
 
 SMALL = load_golden("golden_small")
 SYNTH = load_golden("golden_synthetic")
+SWEEP = load_golden("golden_sweep")
 # the oracle restates the reference operation by operation on the same SciPy, so
 # agreement is at rounding level; 1e-12 leaves room for a different BLAS build
 RTOL = 1e-12
@@ -50,6 +51,60 @@ def test_small(case):
 @pytest.mark.parametrize("case", SYNTH, ids=[c["name"] for c in SYNTH])
 def test_synthetic(case):
     check(case)
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=[c["name"] for c in SWEEP])
+def test_sweep(case):
+    """The README's four-band st x mc sweep (README.md:110-115), one reference run per grid point."""
+    check(case)
+
+
+def test_perturbation_records_are_consistent():
+    """`sens` (round 1's three perturbations) and `spread` (all of them) describe the same runs."""
+    from parity import PERTURB, N_KINDS_BASE, N_KINDS_DEEP, SENS_DETERMINED
+    n_deep = 0
+    for c in SMALL + SYNTH + SWEEP:
+        o = c["out"]
+        if o["llh"] is None:
+            assert 0 <= o["pert_finite"] <= N_KINDS_BASE
+            continue
+        vals = o["pert_llh"]
+        deep = o["sens"] is None or o["sens"] >= SENS_DETERMINED
+        assert len(vals) == (N_KINDS_DEEP if deep else N_KINDS_BASE)
+        n_deep += deep
+        fin = [v for v in vals if v is not None]
+        assert o["pert_fail"] == len(vals) - len(fin)
+        assert o["spread"] == max(abs(v - o["llh"]) / abs(o["llh"]) for v in fin)
+        if o["sens"] is not None:
+            assert o["sens"] == max(abs(v - o["llh"]) / abs(o["llh"]) / PERTURB for v in vals[:3])
+            assert o["spread"] >= o["sens"] * PERTURB * (1 - 1e-12)
+    assert n_deep >= 20
+
+
+def test_oracle_solver_statistics_match_the_traces():
+    """The oracle calls least_squares where the reference does: same number of solves per case as the reference's trace."""
+    import gzip
+    import json
+    import os
+    from conftest import GOLDEN
+    from scipy import optimize
+    traces = {c["name"]: c for c in json.load(gzip.open(os.path.join(GOLDEN, "golden_traces.json.gz"), "rt"))["cases"]}
+    by = {c["name"]: c for c in SMALL + SYNTH + SWEEP}
+    orig = optimize.least_squares
+    for name in ("A4", "A3", "c2_n128_st64_r1", "sw_df_st20_mc9_r0"):
+        log = []
+
+        def spy(*a, **kw):
+            r = orig(*a, **kw)
+            log.append((int(r.nfev), int(r.status)))
+            return r
+        optimize.least_squares = spy
+        try:
+            run(by[name])
+        finally:
+            optimize.least_squares = orig
+        want = [(s["nfev"], s["status"]) for s in traces[name]["solves"]]
+        assert log == want, name
 
 
 def test_appendix_a_literals():

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Table of HIP-vs-reference discrepancies over the golden vectors (run on the GPU box).
 
-    python tools/parity_report.py [--md]
+    python tools/parity_report.py > profiles/rNN_parity_goldens.txt
 
-Columns: relative llk error, the tolerance of tests/parity.py, max relative JAFS
-and lc errors, the reference's own sensitivity `sens` (see make_golden.py)."""
+Per case: relative llk error, the two clauses of the contract (tests/parity.py) - the 1e-9 tolerance (+ rounding floor)
+and 10 x the reference's own measured indeterminacy (`spread`: largest relative change of the reference's llh under
+2^-48 input perturbations, 3 kinds for determined cases, 9 for the others) - which clause the case falls under and
+the FACTOR err / spread for the second; max relative JAFS and lc errors."""
 import contextlib
 import io
 import os
@@ -16,35 +18,56 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from conftest import load_golden                      # noqa: E402
-from parity import determined, engine_args, llk_tol   # noqa: E402
-from misti_amd.engine import MigrationInference       # noqa: E402
+from conftest import load_golden                                   # noqa: E402
+from parity import SELF_FACTOR, engine_args, llk_tol, spread_of    # noqa: E402
+from misti_amd.engine import MigrationInference                    # noqa: E402
 
 
 def main():
     rows = []
-    for f in ("golden_small", "golden_synthetic"):
+    n_tight = n_self = n_out = n_fail_ok = n_fail_bad = 0
+    worst_factor = 0.0
+    for f in ("golden_small", "golden_synthetic", "golden_sweep"):
         for c in load_golden(f):
             o = c["out"]
             args, kw = engine_args(c["in"])
             with contextlib.redirect_stdout(io.StringIO()):
                 m = MigrationInference(*args, **kw)
                 llh = m.JAFSLikelihood(list(c["in"]["params"]))
-            if o["llh"] is None:
-                rows.append((c["name"], "-inf" if llh == -np.inf else "MISMATCH", "", "", "", "", m.status))
+            if o["llh"] is None or llh == -np.inf:
+                both = o["llh"] is None and llh == -np.inf
+                flips = (o.get("pert_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0)
+                ok = both or flips
+                n_fail_ok += ok
+                n_fail_bad += not ok
+                rows.append((c["name"], "ref -inf" if o["llh"] is None else "%.6g" % o["llh"], "hip -inf" if llh == -np.inf else "%.6g" % llh,
+                             "", "", "", "", "", "both fail" if both else ("reference flips" if flips else "MISMATCH")))
                 continue
-            if llh == -np.inf:
-                rows.append((c["name"], "gpu -inf", "", "", "", "%.3g" % (o.get("sens") or -1), m.status))
-                continue
-            tol = llk_tol(o["llh"], c["in"]["sfs"], o["JAFS"], bool(kw.get("unfolded")))
+            err = abs(llh - o["llh"]) / abs(o["llh"])
+            tol = llk_tol(o["llh"], c["in"]["sfs"], o["JAFS"], bool(kw.get("unfolded"))) / abs(o["llh"])
+            spread = spread_of(o)
             ej = np.max(np.abs(np.array(m.JAFS) / np.array(o["JAFS"]) - 1))
             el = np.max(np.abs(np.array(m.lc) / np.array(o["lc"]) - 1))
-            rows.append((c["name"], "%.2e" % (abs(llh - o["llh"]) / abs(o["llh"])), "%.2e" % (tol / abs(o["llh"])),
-                         "%.1e" % ej, "%.1e" % el, "%.3g" % (o.get("sens") or -1), "det" if determined(o) else "indet"))
+            if err <= tol:
+                cls, factor = "1e-9", ""
+                n_tight += 1
+            elif spread is not None and err <= SELF_FACTOR * spread:
+                cls, factor = "self", "%.2f" % (err / spread)
+                worst_factor = max(worst_factor, err / spread)
+                n_self += 1
+            else:
+                cls, factor = "OUTSIDE", "%.2f" % (err / spread) if spread else "inf"
+                n_out += 1
+            rows.append((c["name"], "%.2e" % err, "%.2e" % tol, "%.2e" % spread if spread is not None else "-", factor,
+                         "%.1e" % ej, "%.1e" % el, "%d/%d" % (o.get("pert_fail", 0), len(o.get("pert_llh", []))), cls))
     w = max(len(r[0]) for r in rows)
-    print("%-*s %10s %10s %9s %9s %10s %s" % (w, "case", "llk rel", "llk tol", "JAFS rel", "lc rel", "sens", "class"))
+    print("%-*s %10s %10s %10s %7s %9s %9s %6s %s" % (w, "case", "llk rel", "tol 1e-9", "ref spread", "factor", "JAFS rel", "lc rel", "pfail", "clause"))
     for r in rows:
-        print("%-*s %10s %10s %9s %9s %10s %s" % ((w,) + r))
+        print("%-*s %10s %10s %10s %7s %9s %9s %6s %s" % ((w,) + r))
+    print()
+    print("finite on both sides: %d within 1e-9 (+ floor), %d within %g x the reference's own spread (worst factor %.2f), %d OUTSIDE the contract"
+          % (n_tight, n_self, SELF_FACTOR, worst_factor, n_out))
+    print("failures: %d agree or are reference flips, %d mismatches" % (n_fail_ok, n_fail_bad))
 
 
 if __name__ == "__main__":
