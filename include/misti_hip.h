@@ -187,6 +187,31 @@ int misti_argmax_dev(misti_ctx* ctx, int64_t n_cand, int64_t n_rep, const double
  * Copies n_cand doubles to HOST memory and synchronises the stream. */
 int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
 
+/* ---- batched optimiser ------------------------------------------------------------ */
+/* Replaces MigrationInference.Solve (MigrationInference.py:718-733: SciPy Nelder-Mead on -JAFSLikelihood, xatol =
+ * fatol = tol, maxiter = 1000, started from the -mi / -pu initial values) for n_start starts at once - BASELINE
+ * config 3 runs it from 16 384 random starts.  Every start follows scipy.optimize.minimize(method='Nelder-Mead')
+ * decision for decision (same simplex, same evaluation count), so its result equals SciPy's on the same objective.
+ * Simplices, function values and decisions stay in HBM; per iteration the reflection points of all starts are one
+ * engine batch, their expansion / contraction points a second, shrunk vertices a third; finished starts cost nothing.
+ * Host buffers; synchronous.
+ *   starts      [n_start][n_param]   (n_param >= 1)
+ *   split_time  the split time of every evaluation (fractional allowed)
+ *   jsfs_row    [8]                  the data JSFS (one replicate)
+ *   maxiter     SciPy's maxiter (the reference passes 1000); the evaluation budget is unlimited, as there
+ *   x           [n_start][n_param]   best vertex per start
+ *   llh         [n_start]            its log-likelihood (-inf if no vertex has a value)
+ *   nit, nfev   [n_start] or NULL    SciPy's OptimizeResult.nit / .nfev
+ *   status      [n_start] or NULL    0 converged (both tolerances), 2 iteration budget */
+int misti_nm_solve(misti_ctx* ctx, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                   double xatol, double fatol, int32_t maxiter,
+                   double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status);
+
+/* Work counters of the last misti_nm_solve on this context: [0] iterations issued, [1] batch slots over all iterations
+ * (live starts plus the slack of the two-iterations-old count that sizes the batches; x (2 + n_param) = candidates
+ * handed to the engine after the initial simplices). */
+int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
+
 /* ---- solver trace (parity diagnostics) ---------------------------------------- */
 /* The reference's corrected rates are DEFINED by where SciPy's trust-region iteration stops
  * (CorrectLambda.py:85,260,303,305 -> scipy.optimize.least_squares); tests compare that iteration

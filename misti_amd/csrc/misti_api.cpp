@@ -84,6 +84,10 @@ struct misti_ctx {
     int64_t trace_n = 0, trace_iter_cap = 0;   // candidates / chains covered by the trace of the last batch
     const int32_t* trace_of = nullptr;  // candidate -> chain of the last batch (device)
     hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
+    DevBuf nm_f64, nm_i32;              // batched Nelder-Mead: simplices, points, counters (misti_nm_solve)
+    int32_t* nm_live_host = nullptr;    // pinned: live starts after the last two finished iterations
+    int64_t nm_iterations = 0;          // iterations issued by the last misti_nm_solve
+    int64_t nm_slots = 0;               // and the batch slots they had in total (live starts + the stale-count slack)
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms[3] = {0, 0, 0};
@@ -463,6 +467,9 @@ int misti_destroy(misti_ctx* c) {
                     &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    c->nm_f64.release();
+    c->nm_i32.release();
+    if (c->nm_live_host) (void)hipHostFree(c->nm_live_host);
     for (int w = 0; w < 3; ++w)
         for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -621,6 +628,117 @@ int misti_forward_rates(misti_ctx* c, int64_t n_cand, const double* split, const
     if (pr) HIP_TRY(hipMemcpyAsync(pr, c->st_pr.p, pr_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, c->st_status.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                   double xatol, double fatol, int32_t maxiter,
+                   double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_start < 0) return fail(MISTI_E_ARG, "negative number of starts");
+    if (n_start == 0) return 0;
+    const int N = c->dm.n_param;
+    if (N < 1) return fail(MISTI_E_ARG, "the model has no optimised parameter");
+    if (!starts || !jsfs_row || !x || !llh) return fail(MISTI_E_ARG, "starts / jsfs_row / x / llh is NULL");
+    if (maxiter < 1) return fail(MISTI_E_ARG, "maxiter must be >= 1");
+    if (n_start > INT32_MAX / (8 * (N + 1))) return fail(MISTI_E_LIMIT, "too many starts for one call");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t S = (size_t)n_start, V = (size_t)N + 1;
+    // one allocation per type: simplices and points | counters and slot tables
+    const size_t f64_n = S * V * N * 2 + S * V + S * N * 2 + S * N * N + S + S * V + 2 * S + S * N      // state + split arrays
+                         + S * V + 2 * S + S * N                                                           // llk of the four batches
+                         + S * N + S + 8;                                                                   // inputs / outputs, jsfs row
+    const size_t i32_n = 7 * S + 4;
+    HIP_TRY(c->nm_f64.reserve(f64_n * sizeof(double)));
+    HIP_TRY(c->nm_i32.reserve(i32_n * sizeof(int32_t)));
+    if (!c->nm_live_host) {
+        if (hipHostMalloc((void**)&c->nm_live_host, 4 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->nm_live_host = nullptr;
+            return fail(MISTI_E_HIP, "pinned allocation for the live-start count failed");
+        }
+    }
+    misti::NmState st{};
+    st.S = n_start; st.N = N; st.maxiter = maxiter; st.maxfun = INT64_MAX; st.xatol = xatol; st.fatol = fatol; st.split = split_time;
+    double* d = c->nm_f64.as<double>();
+    st.sim = d; d += S * V * N; st.scratch = d; d += S * V * N; st.fsim = d; d += S * V;
+    st.p1 = d; d += S * N; st.p2 = d; d += S * N; st.p3 = d; d += S * N * N; st.fxr = d; d += S;
+    st.split0 = d; d += S * V; st.split1 = d; d += S; st.split2 = d; d += S; st.split3 = d; d += S * N;
+    double* llk0 = d; d += S * V;
+    double* llk1 = d; d += S;
+    double* llk2 = d; d += S;
+    double* llk3 = d; d += S * N;
+    double* d_starts = d; d += S * N;        // reused for the best vertices at the end
+    double* d_llh = d; d += S;
+    double* d_row = d;
+    int32_t* q = c->nm_i32.as<int32_t>();
+    st.nit = q; q += S; st.nfev = q; q += S; st.done = q; q += S; st.kind = q; q += S; st.shrunk = q; q += S;
+    int32_t* idx[2] = {q, q + S}; q += 2 * S;
+    int32_t* cnt = q;                        // [2] live starts of the iteration in progress / of the next one
+    hipStream_t sm = c->stream;
+    HIP_TRY(hipMemcpyAsync(d_starts, starts, S * N * sizeof(double), hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(d_row, jsfs_row, 8 * sizeof(double), hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 4 * sizeof(int32_t), sm));
+    HIP_TRY(hipMemsetAsync(st.split1, 0xBF, S * sizeof(double), sm));          // all-0xBF bytes: a negative double = "no point in this slot"
+    HIP_TRY(misti::launch_nm_init(st, d_starts, sm));
+    if (int r = run_dev(c, (int64_t)(S * V), st.split0, st.sim, nullptr, 1, d_row, llk0, nullptr, nullptr, nullptr, nullptr)) return r;
+    int cur = 0;
+    st.idx_next = idx[cur]; st.count_next = cnt + cur;
+    HIP_TRY(misti::launch_nm_begin(st, llk0, sm));
+    // The host runs at most two iterations ahead of the device: before issuing iteration k it waits for the event of
+    // iteration k - 2 and reads the count of live starts that iteration left in pinned memory (4 bytes; nothing else of
+    // the search leaves the device).  That count bounds the live starts of iteration k from above - the number only falls -
+    // and sizes its batches; zero -> stop issuing.
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int i = 0; i < 2; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } evg{ev};
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    volatile int32_t* live_host = c->nm_live_host;
+    live_host[0] = live_host[1] = -1;
+    HIP_TRY(hipMemcpyAsync((void*)&live_host[0], cnt + cur, sizeof(int32_t), hipMemcpyDeviceToHost, sm));     // after nm_begin
+    HIP_TRY(hipEventRecord(ev[0], sm));
+    HIP_TRY(hipEventSynchronize(ev[0]));
+    int64_t bound = live_host[0];
+    int64_t issued = 0, slots = 0;
+    for (int it = 0; bound > 0 && it < maxiter; ++it) {
+        const int slot = it & 1;
+        if (it >= 2) {
+            HIP_TRY(hipEventSynchronize(ev[slot]));
+            if (live_host[slot] < bound) bound = live_host[slot];
+            if (bound <= 0) break;
+        }
+        st.idx_cur = idx[cur]; st.count_cur = cnt + cur;
+        st.idx_next = idx[cur ^ 1]; st.count_next = cnt + (cur ^ 1);
+        if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, d_row, llk1, nullptr, nullptr, nullptr, nullptr)) return r;
+        HIP_TRY(misti::launch_nm_reflect(st, bound, llk1, sm));
+        if (int r = run_dev(c, bound, st.split2, st.p2, nullptr, 1, d_row, llk2, nullptr, nullptr, nullptr, nullptr)) return r;
+        HIP_TRY(misti::launch_nm_accept(st, bound, llk2, sm));
+        if (int r = run_dev(c, bound * N, st.split3, st.p3, nullptr, 1, d_row, llk3, nullptr, nullptr, nullptr, nullptr)) return r;
+        HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
+        HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
+        HIP_TRY(misti::launch_nm_finish(st, bound, llk3, sm));
+        HIP_TRY(hipMemcpyAsync((void*)&live_host[slot], cnt + (cur ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+        HIP_TRY(hipEventRecord(ev[slot], sm));
+        cur ^= 1;
+        ++issued;
+        slots += bound;
+    }
+    c->nm_iterations = issued;
+    c->nm_slots = slots;
+    // results (device buffers reused: best vertices over the starts)
+    HIP_TRY(misti::launch_nm_result(st, d_starts, d_llh, st.shrunk, sm));
+    HIP_TRY(hipMemcpyAsync(x, d_starts, S * N * sizeof(double), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipMemcpyAsync(llh, d_llh, S * sizeof(double), hipMemcpyDeviceToHost, sm));
+    if (nit) HIP_TRY(hipMemcpyAsync(nit, st.nit, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (nfev) HIP_TRY(hipMemcpyAsync(nfev, st.nfev, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (status) HIP_TRY(hipMemcpyAsync(status, st.shrunk, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    return 0;
+}
+
+int misti_nm_last_stats(misti_ctx* c, int64_t stats[2]) {
+    if (!c || !stats) return fail(MISTI_E_ARG, "ctx / output is NULL");
+    stats[0] = c->nm_iterations;
+    stats[1] = c->nm_slots;
     return 0;
 }
 

@@ -85,6 +85,45 @@ __host__ __device__ __forceinline__ int32_t solver_word(int nfev, int status, in
 __device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) { return cb.of[cand]; }
 __device__ __forceinline__ int chain_len(const ChainBufs& cb, int64_t ch) { return cb.slot_len[cb.chain_slot[ch]]; }
 
+// Batched Nelder-Mead (misti_nm.hip): everything a start owns, in HBM.  V = N + 1 vertices.
+enum { NM_NONE = 0, NM_REFLECT = 1, NM_EXPAND = 2, NM_CONTRACT = 3, NM_INSIDE = 4 };
+struct NmState {
+    int64_t S;              // starts
+    int N;                  // parameters
+    int maxiter;
+    int64_t maxfun;
+    double xatol, fatol;
+    double split;           // the split time every point is evaluated at
+    // per start
+    double* sim;            // [S][V][N] simplices, best vertex first after every sort
+    double* fsim;           // [S][V]    objective (-llk, +inf where the engine has no value)
+    double* scratch;        // [S][V][N] row permutation buffer of the sort
+    double* fxr;            // [S]
+    int32_t* nit;           // [S] SciPy's `iterations`
+    int32_t* nfev;          // [S] SciPy's fcalls
+    int32_t* done;          // [S] -1 while running; 0 converged, 1 evaluation budget, 2 iteration budget
+    int32_t* kind;          // [S] NM_* of the iteration in progress
+    int32_t* shrunk;        // [S]
+    // per slot of the iteration's batches (live starts compacted)
+    double* p1;             // [S][N]    reflection points
+    double* p2;             // [S][N]    expansion / contraction points
+    double* p3;             // [S][N][N] shrunk vertices
+    double* split0;         // [S * V]   split time per engine candidate of the initial batch
+    double* split1;         // [S]       ... of the reflection batch (negative: no point in this slot)
+    double* split2;         // [S]
+    double* split3;         // [S * N]
+    const int32_t* idx_cur; // [S] slot -> start of the iteration in progress
+    const int32_t* count_cur;   // [1] its number of live starts
+    int32_t* idx_next;      // [S] slot -> start of the next iteration (filled by the kernel that ends this one)
+    int32_t* count_next;    // [1]
+};
+hipError_t launch_nm_init(const NmState& st, const double* starts, hipStream_t stream);
+hipError_t launch_nm_begin(const NmState& st, const double* llk0, hipStream_t stream);
+hipError_t launch_nm_reflect(const NmState& st, int64_t bound, const double* llk1, hipStream_t stream);
+hipError_t launch_nm_accept(const NmState& st, int64_t bound, const double* llk2, hipStream_t stream);
+hipError_t launch_nm_finish(const NmState& st, int64_t bound, const double* llk3, hipStream_t stream);
+hipError_t launch_nm_result(const NmState& st, double* x, double* llh, int32_t* status, hipStream_t stream);
+
 // Replicate epilogue fused into the spectrum kernel up to this many replicates (one launch less per batch).
 constexpr int LLK_INLINE_MAX = 8;
 

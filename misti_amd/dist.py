@@ -65,9 +65,11 @@ def gather_rows(local, n_total, rank, world, interleave=True, group=None):
 def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=None, device=None):
     """Shard candidates over the ranks of the default process group and gather ``llk``.
 
-    ``evaluate(split[n_loc], params[n_loc, P] or None, jsfs[R, 8]) -> llk[n_loc, R]``
-    (a NumPy array or a torch tensor) is the per-rank evaluator - on the GPU box
-    ``Engine.evaluate``; any callable in the CPU tests.
+    ``evaluate(split[n_loc], params[n_loc, P] or None, jsfs[R, 8])`` is the per-rank evaluator: it returns
+    ``llk[n_loc, R]`` (a NumPy array or a torch tensor) or an object with an ``llk`` attribute - on the GPU box
+    ``Engine.evaluate`` (a ``BatchResult``); the oracle in the CPU tests.  With the nccl backend (RCCL) the
+    gathered tensor must live on the rank's GPU: ``device`` defaults to the current CUDA device there.
+    Returns ``llk[n_total, R]`` in candidate order on every rank.
     """
     import torch
     import torch.distributed as dist
@@ -79,7 +81,10 @@ def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=
     idx = shard_indices(n, rank, world, interleave)
     p_loc = None if params is None else np.asarray(params, dtype=np.float64)[idx]
     llk = evaluate(split_time[idx], p_loc, jsfs)
+    llk = getattr(llk, "llk", llk)                       # a BatchResult
     llk = torch.as_tensor(llk, dtype=torch.float64)
+    if device is None and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
     if device is not None:
         llk = llk.to(device)
     return gather_rows(llk, n, rank, world, interleave, group)

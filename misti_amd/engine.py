@@ -202,6 +202,23 @@ class Engine:
     def sync(self):
         _lib.check(self._lib.misti_sync(self._ctx))
 
+    def nm_solve(self, starts, split_time, jsfs_row, tol=1e-4, maxiter=1000):
+        """``misti_nm_solve``: SciPy-exact Nelder-Mead from every row of ``starts`` with the simplices resident in
+        HBM (``MigrationInference.Solve`` for many starts; reference semantics :718-733).
+        Returns dict(x[S][P], llh[S], nit[S], nfev[S], status[S]) - status 0 converged, 2 iteration budget."""
+        st = _f64(starts, (-1, self.n_param))
+        S = st.shape[0]
+        row = _f64(jsfs_row, (8,))
+        x = np.empty((S, self.n_param))
+        llh = np.empty(S)
+        nit, nfev, status = (np.empty(S, dtype=np.int32) for _ in range(3))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.misti_nm_solve(self._ctx, S, ptr(st), float(split_time), ptr(row), float(tol), float(tol), int(maxiter),
+                                            ptr(x), ptr(llh), ptr(nit), ptr(nfev), ptr(status)))
+        stats = (C.c_int64 * 2)()
+        _lib.check(self._lib.misti_nm_last_stats(self._ctx, stats))
+        return dict(x=x, llh=llh, nit=nit, nfev=nfev, status=status, iterations_issued=int(stats[0]), slots=int(stats[1]))
+
     def enable_solver_trace(self, on=True):
         """Record, for the following batches, SciPy-comparable solver statistics per candidate and interval
         (``misti_enable_solver_trace``; see ``solver_trace``)."""
@@ -235,6 +252,47 @@ class Engine:
 
 
 # ------------------------------------------------------------------------------
+def _classes(v, unfolded):
+    """The spectrum classes the likelihood distinguishes: all 7, or folded pairs 0+6, 1+5, 2+4 and 3 (:217-227, :600-609)."""
+    return list(v) if unfolded else [v[0] + v[6], v[1] + v[5], v[2] + v[4], v[3]]
+
+
+def _multinomial_const(counts, unfolded):
+    """log of the multinomial coefficient of the data (llh_const of SetJAFS)."""
+    c = math.lgamma(sum(counts) + 1)
+    for v in _classes(counts, unfolded):          # subtracted one by one, as the reference does (same rounding)
+        c -= math.lgamma(v + 1)
+    return c
+
+
+def _multinomial_logterm(counts, spectrum, unfolded):
+    return sum(c * math.log(p) for c, p in zip(_classes(counts, unfolded), _classes(spectrum, unfolded)))
+
+
+def _band_record(el, sample_date, error):
+    """One ``-mi pop start end value opt`` option -> (pop 0/1, start, end, value, optimised); SetModel's checks :236-247."""
+    pop, start, end, value, opt = int(el[0]) - 1, int(el[1]), int(el[2]), float(el[3]), int(el[4]) == 1
+    if pop not in (0, 1):
+        error("SetModel", "Population index should be 1 or 2.")
+    if start < sample_date:
+        error("SetModel", "Migration start (" + str(start) + ") should be larger than or equal to sample date (" + str(sample_date) + ").")
+    if end <= start:
+        error("SetModel", "Migration start (" + str(start) + ") should be strictly less than migration end (" + str(end) + ").")
+    return pop, start, end, value, opt
+
+
+def _pulse_record(el, sample_date, error):
+    """One ``-pu pop time value opt`` option -> (pop 0/1, time, value, optimised); SetModel's checks :259-271."""
+    pop, t, value, opt = int(el[0]) - 1, int(el[1]), float(el[2]), int(el[3]) == 1
+    if pop not in (0, 1):
+        error("SetModel", "Population index should be 1 or 2.")
+    if t < sample_date:
+        error("SetModel", "Pulse migration time (" + str(t) + ") should be larger than or equal to sample date (" + str(sample_date) + ").")
+    if value < 0 or value > 1:
+        error("SetModel", "Pulse migration rate should be between 0 and 1.")
+    return pop, t, value, opt
+
+
 class MigrationInference:
     """GPU-backed mirror of the reference class (MigrationInference.py:35-739)."""
     COUNT_LLH = 0
@@ -284,8 +342,6 @@ class MigrationInference:
             raise SystemExit(0)
         self.discr = 1
         self.splitT = splitT
-        self.mi = [[None, None] for _ in range(self.numT)]
-        self.pu = [[None, None] for _ in range(self.numT)]
         self.SetModel(mi, pu)
         self.SetJAFS(dataJAFS)
         self.JAFSsize = self.snps
@@ -312,84 +368,60 @@ class MigrationInference:
         raise ModelError(func, text)
 
     def SetJAFS(self, dataJAFS, normalize=False):                               # :202-227
+        """Data spectrum of 8 numbers (total + 7 classes) and the data-only term of the multinomial likelihood."""
         if len(dataJAFS) != 8:
             self.PrintError("SetJAFS", "Unexpected data SFS.")
-        self.snps = sum(dataJAFS[1:])
-        self.dataJAFS = list(dataJAFS[1:])
         self._row = [float(v) for v in dataJAFS]
-        d = self.dataJAFS
-        c = math.lgamma(self.snps + 1)
-        if self.unfolded:
-            for i in range(7):
-                c -= math.lgamma(d[i] + 1)
-        else:
-            c -= math.lgamma(d[0] + d[6] + 1)
-            c -= math.lgamma(d[1] + d[5] + 1)
-            c -= math.lgamma(d[2] + d[4] + 1)
-            c -= math.lgamma(d[3] + 1)
-        self.llh_const = c
+        self.dataJAFS = list(dataJAFS[1:])
+        self.snps = sum(self.dataJAFS)
+        self.llh_const = _multinomial_const(self.dataJAFS, self.unfolded)
 
     def SetModel(self, mis, pus):                                               # :229-289
-        self.optMis, self.optPus = [], []
-        self._fixedMis, self._fixedPus = [], []
-        for row in self.mi:
-            row[0] = row[1] = None
-        for row in self.pu:
-            row[0] = row[1] = None
-        for el in mis:
-            popInd = int(el[0]) - 1
-            if popInd != 0 and popInd != 1:
-                self.PrintError("SetModel", "Population index should be 1 or 2.")
-            migStart = int(el[1])
-            if migStart < self.sampleDate:
-                self.PrintError("SetModel", "Migration start (" + str(migStart) + ") should be larger than or equal to sample date (" + str(self.sampleDate) + ").")
-            migEnd = int(el[2])
-            if migEnd <= migStart:
-                self.PrintError("SetModel", "Migration start (" + str(migStart) + ") should be strictly less than migration end (" + str(migEnd) + ").")
-            migVal = float(el[3])
-            migOpt = int(el[4])
-            for i in range(migStart, migEnd):
-                if self.mi[i][popInd] is not None:
-                    self.PrintError("SetModel", "Migration rate intervals should not overlap.")
-                self.mi[i][popInd] = migVal
-            if migOpt == 1:
-                self.optMis.append([popInd, migStart, migEnd, migVal])
-            else:
-                self._fixedMis.append([popInd, migStart, migEnd, migVal])
-        for el in pus:
-            popInd = int(el[0]) - 1
-            if popInd != 0 and popInd != 1:
-                self.PrintError("SetModel", "Population index should be 1 or 2.")
-            puTime = int(el[1])
-            if puTime < self.sampleDate:
-                self.PrintError("SetModel", "Pulse migration time (" + str(puTime) + ") should be larger than or equal to sample date (" + str(self.sampleDate) + ").")
-            puVal = float(el[2])
-            if puVal < 0 or puVal > 1:
-                self.PrintError("SetModel", "Pulse migration rate should be between 0 and 1.")
-            puOpt = int(el[3])
-            if self.pu[puTime][0] is not None or self.pu[puTime][1] is not None:
-                self.PrintError("SetModel", "Current version allows only single-direction pulse migration at a time.")
-            self.pu[puTime][popInd] = puVal
-            if puOpt == 1:
-                self.optPus.append([popInd, puTime, puVal])
-            else:
-                self._fixedPus.append([popInd, puTime, puVal])
-        for arr in (self.mi, self.pu):
-            for row in arr:
-                for k in (0, 1):
-                    if row[k] is None:
-                        row[k] = 0.0
-        self.optMisSize = len(self.optMis)
-        self.optPusSize = len(self.optPus)
+        """``-mi`` / ``-pu`` descriptors -> band and pulse records (``_bands``, ``_pulses``; what the C ABI takes)
+        and, derived from them, the per-interval tables ``mi`` / ``pu`` and the lists ``optMis`` / ``optPus`` the
+        reference's callers read.  Errors are the reference's (message and exit status 0)."""
+        self._bands = [_band_record(el, self.sampleDate, self.PrintError) for el in mis]
+        self._pulses = [_pulse_record(el, self.sampleDate, self.PrintError) for el in pus]
+        for pop, start, end, _, _ in self._bands:
+            if end > self.numT:                      # the reference runs off the end of its table here (IndexError)
+                self.PrintError("SetModel", "Migration end (" + str(end) + ") is beyond the last time interval (" + str(self.numT) + ").")
+        for pop, t, _, _ in self._pulses:
+            if t >= self.numT:
+                self.PrintError("SetModel", "Pulse migration time (" + str(t) + ") is beyond the last time interval (" + str(self.numT - 1) + ").")
+        taken = set()
+        for pop, start, end, _, _ in self._bands:
+            cells = {(pop, t) for t in range(start, end)}
+            if cells & taken:
+                self.PrintError("SetModel", "Migration rate intervals should not overlap.")
+            taken |= cells
+        if len({t for _, t, _, _ in self._pulses}) != len(self._pulses):
+            self.PrintError("SetModel", "Current version allows only single-direction pulse migration at a time.")
+        self.optMis = [[pop, start, end, val] for pop, start, end, val, opt in self._bands if opt]
+        self.optPus = [[pop, t, val] for pop, t, val, opt in self._pulses if opt]
+        self._fixedMis = [[pop, start, end, val] for pop, start, end, val, opt in self._bands if not opt]
+        self._fixedPus = [[pop, t, val] for pop, t, val, opt in self._pulses if not opt]
+        self.optMisSize, self.optPusSize = len(self.optMis), len(self.optPus)
+        self._fill_tables([b[3] for b in self.optMis] + [q[2] for q in self.optPus])
+
+    def _fill_tables(self, values):
+        """Per-interval tables from the records; optimised bands / pulses take ``values`` (bands first, in option order)."""
+        self.mi = [[0.0, 0.0] for _ in range(self.numT)]
+        self.pu = [[0.0, 0.0] for _ in range(self.numT)]
+        free = iter(values)
+        rate_of = {}
+        for k, (pop, start, end, val, opt) in enumerate(self._bands):
+            if opt:
+                rate_of[k] = next(free)
+        for k, (pop, start, end, val, opt) in enumerate(self._bands):
+            for t in range(start, end):
+                self.mi[t][pop] = rate_of.get(k, val)
+        for pop, t, val, opt in self._pulses:
+            self.pu[t][pop] = next(free) if opt else val
 
     def MapParameters(self, params):                                            # :291-298
         if len(params) != self.optMisSize + self.optPusSize:
             self.PrintError("MapParameters", "Incorrect number of parameters.")
-        for i in range(self.optMisSize):
-            for j in range(self.optMis[i][1], self.optMis[i][2]):
-                self.mi[j][self.optMis[i][0]] = params[i]
-        for i in range(self.optPusSize):
-            self.pu[self.optPus[i][1]][self.optPus[i][0]] = params[self.optMisSize + i]
+        self._fill_tables(list(params))
 
     # -- the hot path ----------------------------------------------------------------
     def JAFSLikelihood(self, mu):                                               # :566-614
@@ -451,19 +483,9 @@ class MigrationInference:
         return self._engine.evaluate(split_times, params, [self._row] if jsfs_rows is None else jsfs_rows, **kw)
 
     def MaximumLLHFunction(self):                                               # :696-711
-        llh = self.llh_const
+        """Likelihood of the data under its own (saturated) spectrum: the upper bound of JAFSLikelihood."""
         tot = sum(self.dataJAFS)
-        j = [v / tot for v in self.dataJAFS]
-        d = self.dataJAFS
-        if not self.unfolded:
-            llh += (d[0] + d[6]) * math.log(j[0] + j[6])
-            llh += (d[1] + d[5]) * math.log(j[1] + j[5])
-            llh += (d[2] + d[4]) * math.log(j[2] + j[4])
-            llh += d[3] * math.log(j[3])
-        else:
-            for i in range(7):
-                llh += d[i] * math.log(j[i])
-        return llh
+        return self.llh_const + _multinomial_logterm(self.dataJAFS, [v / tot for v in self.dataJAFS], self.unfolded)
 
     def ObjectiveFunction(self, mu):                                            # :713-716
         res = -self.JAFSLikelihood(mu)

@@ -141,6 +141,15 @@ def solve_batched(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
     return r.x, -r.fun, r
 
 
+def solve_batched_dev(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
+    """``solve_batched`` with the simplices resident on the device (``misti_nm_solve``): no host round trip per
+    iteration - per iteration three engine batches and four one-thread-per-start kernels on the engine's stream.
+    Same decisions as SciPy's Nelder-Mead, hence the same result as ``solve_batched`` / ``MigrationInference.Solve``.
+    Returns (params[S, P], llh[S], dict with nit, nfev, status)."""
+    r = engine.nm_solve(starts, split_time, jsfs_row, tol=tol, maxiter=maxiter)
+    return r["x"], r["llh"], r
+
+
 def bootstrap_split_interval(llk, split_values, level=0.95):
     """Confidence interval of the split time from bootstrap replicates, as in the reference's
     ``test.bs/bs_conf_int.ipynb``: per replicate the arg-max split over the scan, then a

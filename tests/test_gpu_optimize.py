@@ -86,3 +86,74 @@ def test_bootstrap_scan_on_device_matches_host_reduction():
         e.sync()
     assert np.array_equal(best_h, best_d) and mean_h == mean_d and ci_h == ci_d
     assert best.cpu().tolist() == [1, -1, -1] and val.cpu().tolist()[0] == 3.0
+
+
+def test_device_resident_search_equals_host_search_and_scipy(cfg3):
+    """misti_nm_solve (simplices, values and decisions in HBM) against the host-side batched search and SciPy itself:
+    same best vertex, same value, same nit and nfev for every start."""
+    from scipy import optimize
+    from misti_amd.optimize import solve_batched, solve_batched_dev
+    w, eng = cfg3
+    split = float(w.split_time[0])
+    x_h, llh_h, r_h = solve_batched(eng, split, w.params, w.jsfs[0], tol=1e-4, maxiter=1000)
+    x_d, llh_d, r_d = solve_batched_dev(eng, split, w.params, w.jsfs[0], tol=1e-4, maxiter=1000)
+    assert np.array_equal(x_d, x_h) and np.array_equal(llh_d, llh_h)
+    assert np.array_equal(r_d["nit"], r_h.nit) and np.array_equal(r_d["nfev"], r_h.nfev)
+    assert (r_d["status"] == 0).all() == bool(r_h.converged.all())
+    for i in (0, 7, 23):
+        def obj(mu):
+            if (np.asarray(mu) < 0).any():
+                return np.inf
+            return -float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+        ref = optimize.minimize(obj, w.params[i], method="Nelder-Mead", options={"xatol": 1e-4, "fatol": 1e-4, "maxiter": 1000})
+        assert np.array_equal(ref.x, x_d[i]) and -ref.fun == llh_d[i] and ref.nit == r_d["nit"][i] and ref.nfev == r_d["nfev"][i]
+
+
+def test_device_search_iteration_budget_and_fractional_split(cfg3):
+    """maxiter as SciPy counts it (iterations start at 1: at most maxiter - 1 are run), on a fractional split time."""
+    from scipy import optimize
+    from misti_amd.optimize import solve_batched_dev
+    w, eng = cfg3
+    split = float(w.split_time[0]) - 0.5
+    x, llh, r = solve_batched_dev(eng, split, w.params[:4], w.jsfs[0], tol=1e-9, maxiter=12)
+    assert (r["status"] == 2).all() and (r["nit"] == 12).all()
+    def obj(mu):
+        if (np.asarray(mu) < 0).any():
+            return np.inf
+        return -float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = optimize.minimize(obj, w.params[2], method="Nelder-Mead", options={"xatol": 1e-9, "fatol": 1e-9, "maxiter": 12})
+    assert np.array_equal(ref.x, x[2]) and -ref.fun == llh[2] and ref.nfev == r["nfev"][2]
+
+
+def test_device_search_at_config3_size():
+    """BASELINE config 3: 16 384 random starts, two optimised bands, searched in one call with the simplices in HBM;
+    32 sampled starts bit-equal to scipy.optimize.minimize(method='Nelder-Mead') on the GPU objective."""
+    from scipy import optimize
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    from misti_amd.optimize import solve_batched_dev
+    w = workloads.config3(lambda *a: truth_spectrum(*a))
+    assert w.n_cand == 16384
+    split = float(w.split_time[0])
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as eng:
+        x, llh, r = solve_batched_dev(eng, split, w.params, w.jsfs[0], tol=1e-4, maxiter=1000)
+        assert np.isfinite(llh).mean() > 0.99
+        assert (r["status"] == 0).mean() > 0.99
+        start_llh = eng.evaluate(np.full(w.n_cand, split), w.params, w.jsfs).llk[:, 0]
+        ok = np.isfinite(start_llh)
+        assert (llh[ok] >= start_llh[ok]).all()
+        rng = np.random.default_rng(11)
+        for i in rng.choice(w.n_cand, 32, replace=False):
+            def obj(mu):
+                if (np.asarray(mu) < 0).any():
+                    return np.inf
+                v = float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+                return -v if np.isfinite(v) else np.inf
+            ref = optimize.minimize(obj, w.params[i], method="Nelder-Mead", options={"xatol": 1e-4, "fatol": 1e-4, "maxiter": 1000})
+            assert np.array_equal(ref.x, x[i]) and -ref.fun == llh[i], (i, ref.x, x[i])
+            assert ref.nit == r["nit"][i] and ref.nfev == r["nfev"][i]
+    # the surface has one dominant basin: most starts end within the tolerance of the best value found
+    assert (llh >= np.max(llh) - 1e-3).mean() > 0.8
