@@ -42,7 +42,12 @@ def build(force=False, verbose=False, extra=(), out=None):
     if not force and not out and not stale():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-           "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+           "-Wall", "-Wno-unused-function"]
+    # Contraction within a source expression only (clang's `on`), not `fast`: with `fast` the backend fuses a multiply
+    # and an add wherever its DAG happens to bring them together, which depends on inlining context - two template
+    # instantiations of the same source could then round differently, and a chain's bits would depend on how many
+    # chains share its wavefront.  With `on` every expression is fused (or not) as written, in every instantiation.
+    cmd += ["-ffp-contract=" + os.environ.get("MISTI_FP_CONTRACT", "on")]
     cmd += list(extra)
     if os.environ.get("MISTI_STAMP2"):         # diagnostic build: stage cycle counts of the spectrum kernel in place of the spectrum
         cmd += ["-DMISTI_STAMP2=1"]

@@ -75,9 +75,10 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {
 // Everything "uniform" is uniform within a group; cross-lane traffic never leaves a group.
 template <int GROUP>
 __device__ __forceinline__ double gbcast(double v, int j) {
-    if (GROUP == 64) {                       // one candidate per wave: scalar broadcast, no LDS crossbar round trip
-        int lo = __builtin_amdgcn_readlane(__double2loint(v), j);
-        int hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    if (GROUP == 64) {                       // one candidate per wave: scalar broadcast (j wave-uniform), no LDS crossbar round trip
+        const int ju = __builtin_amdgcn_readfirstlane(j);
+        int lo = __builtin_amdgcn_readlane(__double2loint(v), ju);
+        int hi = __builtin_amdgcn_readlane(__double2hiint(v), ju);
         return __hiloint2double(hi, lo);
     }
     return __shfl(v, (lane_id() - lane_id() % GROUP) + j, 64);     // GROUP = 6: ten items per wave, lanes 60-63 idle
@@ -96,6 +97,14 @@ __device__ __forceinline__ void lds_order() {
     __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the LDS writes before are done; no wait for global stores
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+// A branch condition that is the same in every lane - everything of a chain is, when the chain has the wave to itself
+// (GROUP == 64) - handed to the compiler as a SCALAR: it then branches with s_cbranch_scc instead of masking lanes off
+// (s_and_saveexec / s_or exec around every block, and copies of all loop-carried state at every divergent loop edge:
+// that plumbing was about a fifth of the correction kernel's instructions).  With several chains per wave the condition
+// really differs between lanes and is left alone.
+template <int GROUP>
+__device__ __forceinline__ bool uni(bool c) { return GROUP == 64 ? (bool)__builtin_amdgcn_readfirstlane((int)c) : c; }
 
 __device__ __forceinline__ void lds_fence() {
     // one wave owns its LDS slice: ordering only has to be kept by the compiler
@@ -176,7 +185,7 @@ struct Model {
 // v <- exp(M) v by uniformisation.  Every lane carries its own (l, v); the trip
 // count is wave-uniform (bound from the largest q in the wave).
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
-struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0; };
+struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0, spec = 0; };
 // K terms of the Taylor series of exp(M) v for the pair generator, fully unrolled.
 template <int K>
 __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double mu0, double mu1, double v[3], Diag& dg) {
@@ -202,12 +211,12 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
 // with one-directional migration) the forward-difference lanes then perform bit-identical
 // arithmetic on the remaining components, so the Jacobian column is exactly zero - as it is in
 // the reference, whose solver leaves that rate untouched.
-__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], double q, double neg, bool ok, Diag& dg) {
+__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], double q, double neg, bool ok, Diag& dg, bool& guard) {
     if (!ok) { l0 = 0.0; l1 = 0.0; }
     double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1;
     double nbmax = q + neg;                                  // >= ||N||_1 (column sums q - l0, q - l1, q)
     if (!(nbmax < 1e300)) {                                  // overflowing iterate: report non-finite (TRF shrinks the step)
-        dg.guard = true;
+        guard = true;
         v[0] = v[1] = v[2] = NAN;
         return;
     }
@@ -310,7 +319,9 @@ __device__ __forceinline__ double rcp64(double x) {
     return r;
 }
 __device__ __forceinline__ double sqrt64(double x) {
-    if (!(x > 0.0)) return x == 0.0 ? 0.0 : sqrt(x);      // 0, negative, NaN: exact library semantics
+    // straight-line: the solver's bookkeeping is one dependent instruction stream, every branch costs it a handful of
+    // scalar instructions.  rsq(0) = inf and rsq(inf) = 0 make the Newton steps NaN: those two inputs are passed through;
+    // negative and NaN inputs give NaN by themselves (rsq), as sqrt() does.
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
@@ -318,7 +329,8 @@ __device__ __forceinline__ double sqrt64(double x) {
     r = fma(-h, g, 0.5);
     g = fma(g, r, g); h = fma(h, r, h);
     double d = fma(-g, g, x);
-    return fma(d, h, g);
+    const double s = fma(d, h, g);
+    return (x == 0.0 || x == INFINITY) ? x : s;
 }
 
 // ------------------------------------------------------- least squares -------
@@ -677,33 +689,32 @@ struct PairProblem {
     double tgt[2];         // cpfit: exp(-lh_k) * s_k (:141); default fit: one-population expected coalescence time (:74-77)
 };
 
-template <bool CPFIT, int GROUP>
-__device__ __forceinline__ void pair_batch(const PairProblem& pb, const double xe[2], int sub, Diag& dg,
-                                           double f[2], double J[2][2], double w[3], bool& finite) {
-    const double x0 = xe[0], x1 = xe[1];
+// One residual evaluation per lane: this lane's role r (= 2 e + k, see PairProblem) at ITS point (x0, x1).  The six
+// lanes of a slot share the point; different slots of a wave may hold different points (the needed one and guesses of
+// its successors, see correct_body).  A pure function of (pb, point, role): what else sits in the wave changes no bit.
+template <bool CPFIT>
+__device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, double x1, int role, Diag& dg, double& res, double w[3], bool& guard) {
     const double h0 = fd_step(x0), h1 = fd_step(x1);
     const double xa = x0 + h0, xb = x1 + h1;
-    const double dx0 = xa - x0, dx1 = xb - x1;      // recomputed as exactly representable (_numdiff.py)
-    const int e = sub >> 1, k = sub & 1;
+    const int e = role >> 1, k = role & 1;
     const double l0 = (e == 1) ? xa : x0;
     const double l1 = (e == 2) ? xb : x1;
     const bool ok = isfinite(x0) && isfinite(x1);
-    // group-uniform uniformisation rate: the largest over the three evaluation points
+    // slot-uniform uniformisation rate: the largest over the three evaluation points
     const double m0 = fmax(x0, xa), m1 = fmax(x1, xb);
     const double q = fmax(fmax(2.0 * pb.mu0 + m0, 2.0 * pb.mu1 + m1), fmax(pb.mu0 + pb.mu1, 0.0));
     const double neg = fmax(0.0, fmax(-fmin(x0, xa), -fmin(x1, xb)));
     const double sk = k ? pb.s[1] : pb.s[0];
-    double res;
     if (CPFIT) {
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
         for (int i = 0; i < 3; ++i) w[i] = k ? pb.P[1][i] : pb.P[0][i];
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg);
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
         res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
         double pn[3];
         for (int i = 0; i < 3; ++i) { pn[i] = (k ? pb.P[1][i] : pb.P[0][i]) / sk; w[i] = pn[i]; }
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg);
+        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
         double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
         double dd[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
         double y[3], vec1[3], vec2[3];
@@ -716,9 +727,18 @@ __device__ __forceinline__ void pair_batch(const PairProblem& pb, const double x
         // the state vector handed on is exp(M) applied to the unnormalised vector
         w[0] *= sk; w[1] *= sk; w[2] *= sk;
     }
-    const double fb0 = gbcast<GROUP>(res, 0), fb1 = gbcast<GROUP>(res, 1);
-    const double fa0 = gbcast<GROUP>(res, 2), fa1 = gbcast<GROUP>(res, 3);
-    const double fc0 = gbcast<GROUP>(res, 4), fc1 = gbcast<GROUP>(res, 5);
+}
+
+// Residuals and forward-difference Jacobian at the point xe from the six lanes base .. base + 5 that evaluated it.
+template <int GROUP>
+__device__ __forceinline__ void pair_collect(double res, const double xe[2], int base, double f[2], double J[2][2], bool& finite) {
+    const double x0 = xe[0], x1 = xe[1];
+    const double h0 = fd_step(x0), h1 = fd_step(x1);
+    const double xa = x0 + h0, xb = x1 + h1;
+    const double dx0 = xa - x0, dx1 = xb - x1;      // recomputed as exactly representable (_numdiff.py)
+    const double fb0 = gbcast<GROUP>(res, base + 0), fb1 = gbcast<GROUP>(res, base + 1);
+    const double fa0 = gbcast<GROUP>(res, base + 2), fa1 = gbcast<GROUP>(res, base + 3);
+    const double fc0 = gbcast<GROUP>(res, base + 4), fc1 = gbcast<GROUP>(res, base + 5);
     const double r0 = rcp64(dx0), r1 = rcp64(dx1);
     f[0] = fb0; f[1] = fb1;
     J[0][0] = (fa0 - fb0) * r0; J[1][0] = (fa1 - fb1) * r0;
@@ -729,31 +749,33 @@ __device__ __forceinline__ void pair_batch(const PairProblem& pb, const double x
 // Next trial step of trf_no_bounds (trf.py:469-486): Gauss-Newton step when the Jacobian has
 // full rank and the step lies in the trust region (solve_lsq_trust_region, common.py:116-125),
 // otherwise the regularised step from the SVD.  Returns the predicted reduction.
+template <int GROUP>
 __device__ __forceinline__ double next_step(const double J[2][2], const double f[2], const double g[2], double Delta, double& alpha,
-                                            Svd2& sv, bool& have_sv, double p[2], int& lm) {
+                                            Svd2& sv, bool& have_sv, double p[2], int& lm, int& axis) {
     const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
     const double F = (J[0][0] * J[0][0] + J[0][1] * J[0][1]) + (J[1][0] * J[1][0] + J[1][1] * J[1][1]);
-    bool done = false;
     // A structurally decoupled rate (Jacobian column exactly zero, see pair_expv): J has rank one,
     // solve_lsq_trust_region takes its regularised branch and ALWAYS rescales the step to the
     // trust radius (common.py:160-164), so the step is (0, -sign(g1) Delta) whatever alpha the
     // secular iteration ends with - and alpha is only a starting guess for the next call.
     const bool z0 = J[0][0] == 0.0 && J[1][0] == 0.0, z1 = J[0][1] == 0.0 && J[1][1] == 0.0;
-    if (z0 != z1) {
-        const int k = z0 ? 1 : 0;
-        p[1 - k] = 0.0;
-        p[k] = g[k] > 0 ? -Delta : Delta;
+    const bool rank1 = z0 != z1;
+    const int k = z0 ? 1 : 0;
+    axis = rank1 ? k : -1;
+    const double gk = z0 ? g[1] : g[0];
+    const double pk = gk > 0 ? -Delta : Delta;
+    // Gauss-Newton step (computed unconditionally - straight-line code - and used when J certainly has full rank and the
+    // step lies inside the trust region): s_max^2 <= F <= 2 s_max^2 and s_min = |det| / s_max, so full rank
+    // (s_min > 2 eps s_max) is certain if |det| > 2 eps F
+    const double rd = rcp64(det);
+    const double p0 = -(J[1][1] * f[0] - J[0][1] * f[1]) * rd;
+    const double p1 = -(J[0][0] * f[1] - J[1][0] * f[0]) * rd;
+    const bool gn = !rank1 && fabs(det) > 2.0 * LSQ_EPS * 2.0 * F && p0 * p0 + p1 * p1 <= Delta * Delta;
+    if (uni<GROUP>(rank1 || gn)) {
+        p[0] = rank1 ? (z0 ? 0.0 : pk) : p0;
+        p[1] = rank1 ? (z0 ? pk : 0.0) : p1;
         alpha = 0.0;
-        done = true;
-    }
-    // s_max^2 <= F <= 2 s_max^2 and s_min = |det| / s_max: full rank (s_min > 2 eps s_max) is certain if |det| > 2 eps F
-    if (!done && fabs(det) > 2.0 * LSQ_EPS * 2.0 * F) {
-        const double rd = rcp64(det);
-        const double p0 = -(J[1][1] * f[0] - J[0][1] * f[1]) * rd;
-        const double p1 = -(J[0][0] * f[1] - J[1][0] * f[0]) * rd;
-        if (p0 * p0 + p1 * p1 <= Delta * Delta) { p[0] = p0; p[1] = p1; alpha = 0.0; done = true; }
-    }
-    if (!done) {
+    } else {
         if (!have_sv) { sv = svd_mx2<2>(J, f); have_sv = true; }
         solve_tr(sv, 2, Delta, alpha, p);
         lm += 1;
@@ -767,9 +789,10 @@ __device__ __forceinline__ double next_step(const double J[2][2], const double f
 // wave-uniform except inside pair_eval.  Returns false on "correction failed".
 struct PairState { double p[2][3]; };
 
+template <int GROUP = 1>
 __device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu1) {
     double r = pu0 + pu1;                                        // :315-323
-    if (!(r > 0)) return;
+    if (uni<GROUP>(!(r > 0))) return;
     int a = pu0 > 0 ? 0 : 1, b = 1 - a;
     for (int k = 0; k < 2; ++k) {
         double pa = ps.p[k][a], pb = ps.p[k][b], pc = ps.p[k][2];
@@ -873,7 +896,8 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
             for (int k = 0; k < 2; ++k) {
                 double v[3] = {ps.p[k][0], ps.p[k][1], ps.p[k][2]};
                 const double before = (v[0] + v[1]) + v[2];
-                pair_expv(a0, a1, b0, b1, v, q, 0.0, true, dg);
+                bool guard_unused = false;
+                pair_expv(a0, a1, b0, b1, v, q, 0.0, true, dg, guard_unused);
                 const double nc = (v[0] + v[1]) + v[2];
                 const double seen = -log(nc / before) / T;
                 if (k == 0) l0 = seen; else l1 = seen;
@@ -978,10 +1002,20 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     int nfev = 0;
     bool first = false, in_solve = false, have_sv = false;
     Svd2 sv;
+    // speculative slots (one chain per wave only): SPEC_SLOTS x 6 lanes, slot 0 = the point the solver asked for
+#ifndef MISTI_SPEC
+#define MISTI_SPEC 1
+#endif
+    constexpr bool SPEC = MISTI_SPEC && (GROUP == 64) && !TAIL;
+    constexpr int SPEC_SLOTS = 8;
+    const int slot_of_lane = SPEC ? (lane < 6 * SPEC_SLOTS ? lane / 6 : 0) : 0;
+    const int role = SPEC ? (lane < 6 * SPEC_SLOTS ? lane % 6 : (lane - 6 * SPEC_SLOTS) % 6) : sub;   // lanes beyond the slots repeat slot 0
+    int spec_axis = -1;        // >= 0: the solver is in the exact rank-one regime and moves along this axis
+    int vk_base = 0;           // first lane of the slot whose state vectors vk belong to the accepted point
 
     auto finish_interval = [&](double lc0, double lc1, int32_t word) -> bool {       // :345-350; false = correction failed
         if (sub == 0) { lc_w[2 * t] = lc0; lc_w[2 * t + 1] = lc1; if (sv_w) sv_w[t] = word; }
-        if (!(lc0 > 0) || !(lc1 > 0)) {
+        if (uni<GROUP>(!(lc0 > 0) || !(lc1 > 0))) {
             status = (isnan(lc0) || isnan(lc1)) ? MISTI_NUMERIC : MISTI_CORR_FAILED;
             return false;
         }
@@ -1000,7 +1034,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     };
 
 #ifdef MISTI_STAMP
-    long long c_adv = 0, c_batch = 0, c_book = 0, c_t0 = 0;
+    long long c_adv = 0, c_batch = 0, c_book = 0, c_t0 = 0, c_collect = 0, c_update = 0, c_next = 0;
 #define STAMP(acc) { long long now_ = clock64(); acc += now_ - c_t0; c_t0 = now_; }
 #else
 #define STAMP(acc)
@@ -1024,16 +1058,16 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 #ifdef MISTI_STAMP
     c_t0 = clock64();
 #endif
-    while (active) {
-        if (!in_solve) {
+    while (uni<GROUP>(active)) {
+        if (uni<GROUP>(!in_solve)) {
             // ---- advance over intervals until one needs the iterative solver ----------
-            while (t < G.split) {
+            while (uni<GROUP>(t < G.split)) {
                 double pu0, pu1, mu0, mu1, eh0 = 0.0, eh1 = 0.0;
                 if (pre) { const double* q = pre + 6 * t; mu0 = q[0]; mu1 = q[1]; pu0 = q[2]; pu1 = q[3]; eh0 = q[4]; eh1 = q[5]; }
                 else { mod.pulse(t, pu0, pu1); mod.mig(t, mu0, mu1); }
-                pulse_pairs(ps, pu0, pu1);                                              // :315-323
+                pulse_pairs<GROUP>(ps, pu0, pu1);                                       // :315-323
                 double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
-                if (!correct) { if (!finish_interval(lh0, lh1, 0)) break; continue; }    // :325-326
+                if (!correct) { if (uni<GROUP>(!finish_interval(lh0, lh1, 0))) break; continue; }    // :325-326
                 T = G.T(t);
                 const double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
                 const double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
@@ -1042,7 +1076,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                     for (int i = 0; i < 3; ++i) { double d = ps.p[0][i] / s0 - ps.p[1][i] / s1; mix += d * d; }
                     if (sqrt(mix) < m.mixture_th) { finish_interval(-1.0, -1.0, 0); break; }
                 }
-                if (mu0 + mu1 < 1e-10) {
+                if (uni<GROUP>(mu0 + mu1 < 1e-10)) {
                     double lc0, lc1;
                     int32_t word = solver_word(0, 0, 1);
                     if (CPFIT) {
@@ -1054,7 +1088,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                         if (!pre) { eh0 = exp(-lh0 * T); eh1 = exp(-lh1 * T); }
                         double X1 = eh0 - C1, X2 = eh1 - C2;
                         double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
-                        if (y0 > 0 && y1 > 0) { lc0 = -log(y0) / T; lc1 = -log(y1) / T; }
+                        if (uni<GROUP>(y0 > 0 && y1 > 0)) { lc0 = -log(y0) / T; lc1 = -log(y1) / T; }
                         else { lc0 = lc1 = -1.0; }
                     } else {
                         // SolveNoMigration :253-264: bounded 2-D fit of the conditional expected coalescence time
@@ -1076,19 +1110,19 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                     }
                     double e0 = exp(-lc0 * T), e1 = exp(-lc1 * T);
                     for (int k = 0; k < 2; ++k) { ps.p[k][0] *= e0; ps.p[k][1] *= e1; }
-                    if (!finish_interval(lc0, lc1, word)) break;
+                    if (uni<GROUP>(!finish_interval(lc0, lc1, word))) break;
                     continue;
                 }
                 // migrating interval: set the 2x2 problem up (:278-305) and leave the advance loop
                 double n0 = 0, n1 = 0, nd = 0;
                 for (int i = 0; i < 3; ++i) { n0 += ps.p[0][i] * ps.p[0][i]; n1 += ps.p[1][i] * ps.p[1][i]; double d = ps.p[0][i] - ps.p[1][i]; nd += d * d; }
                 bool averaged = false;
-                if (nd < 0.0004 * fmin(n0, n1)) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; averaged = true; }   // normD < 0.02 min(norms), squared
+                if (uni<GROUP>(nd < 0.0004 * fmin(n0, n1))) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; averaged = true; }   // normD < 0.02 min(norms), squared
                 pb.mu0 = mu0 * T; pb.mu1 = mu1 * T;                                      // stretch :293-298
                 const double lhs0 = lh0 * T, lhs1 = lh1 * T;
                 for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
                 pb.s[0] = s0; pb.s[1] = s1;
-                if (!pre || averaged) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
+                if (uni<GROUP>(!pre || averaged)) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
                 if (CPFIT) { pb.tgt[0] = eh0 * s0; pb.tgt[1] = eh1 * s1; }
                 else {
                     double pa = eh0, pbb = eh1;                                          // ExpectedCoalTimeOnePopTmp, T = 1
@@ -1096,79 +1130,120 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                     pb.tgt[1] = 1.0 / lhs1 - 1.0 / (1.0 / pbb - 1.0);
                 }
                 xe[0] = lhs0; xe[1] = lhs1;
-                first = true; in_solve = true; have_sv = false;
+                first = true; in_solve = true; have_sv = false; spec_axis = -1;
                 break;
             }
-            if (!in_solve) { active = false; break; }              // reached the split, or failed
+            if (uni<GROUP>(!in_solve)) { active = false; break; }  // reached the split, or failed
         }
         STAMP(c_adv)
-        // ---- one residual batch at xe -------------------------------------------------
-        double fn[2], Jn[2][2], w[3];
-        bool finite;
-        if (it_w && sub == 0) {
-            const int i = first ? 0 : nfev;
-            if (i < MISTI_TRACE_MAX_ITER) { double* r = it_w + ((int64_t)t * MISTI_TRACE_MAX_ITER + i) * 2; r[0] = xe[0]; r[1] = xe[1]; }
-        }
-        pair_batch<CPFIT, GROUP>(pb, xe, sub, dg, fn, Jn, w, finite);
-        dg.evals += 1;
-        STAMP(c_batch)
-        // ---- trust-region bookkeeping (trf_no_bounds) -----------------------------------
-        bool accept = false, done = false;
-        int term = 0;
-        double cost_new = 0.5 * (fn[0] * fn[0] + fn[1] * fn[1]);
-        if (first) {
-            first = false;
-            nfev = 1;
-            if (!finite) { status = MISTI_NUMERIC; active = false; break; }   // SciPy raises on a non-finite start
-            Delta = sqrt64(xe[0] * xe[0] + xe[1] * xe[1]);
-            if (Delta == 0) Delta = 1.0;
-            alpha = 0.0;
-            accept = true;
-        } else {
-            ++nfev;
+        // ---- one residual batch: the point the solver needs in slot 0, guesses of its successor in the other slots ----
+        // One chain per wave leaves 58 of 64 lanes idle during an evaluation.  In the exact rank-one regime (a rate
+        // decoupled after a runaway: its Jacobian column is exactly zero and the solver moves along the other axis by
+        // +-Delta, see next_step) the point after the trial xe is one of a handful - radius doubled, kept or quartered,
+        // either sign, from xe if the trial is accepted or from x if it is rejected - all computable before the trial's
+        // residual is known.  They are evaluated in the idle lanes (slot s = lanes 6 s .. 6 s + 5) by the same pure
+        // function of the point, so when the bookkeeping then asks for one of them its six residuals are already there:
+        // two solver steps per pass instead of one, bit for bit the same iteration.  A guess never consumed costs nothing.
+        double px0 = xe[0], px1 = xe[1];
+        if (SPEC && spec_axis >= 0 && !first) {
             const double sn2 = p[0] * p[0] + p[1] * p[1];
-            if (!finite) { Delta = 0.25 * sqrt64(sn2); }
-            else {
-                const double actual = cost - cost_new;
-                double ratio;
-                if (predicted > 0) ratio = actual * rcp64(predicted);
-                else if (predicted == 0 && actual == 0) ratio = 1.0;
-                else ratio = 0.0;
-                double Delta_new = Delta;                                    // update_tr_radius, common.py:222-245
-                if (ratio < 0.25) Delta_new = 0.25 * sqrt64(sn2);
-                else if (ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) Delta_new = 2.0 * Delta;
-                const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;  // check_termination, common.py:705-717
-                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt64(x[0] * x[0] + x[1] * x[1]));
-                const bool x_ok = sn2 < lim * lim;
-                term = (f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0;
-                if (term == 0) { if (alpha != 0.0) alpha *= Delta * rcp64(Delta_new); Delta = Delta_new; }
-                accept = actual > 0;
+            const double dq = 0.25 * sqrt64(sn2);                               // the radius after a poor step (update_tr_radius)
+            const double mag = slot_of_lane <= 2 ? 2.0 * Delta : (slot_of_lane <= 4 ? Delta : dq);
+            const bool from_x = slot_of_lane == 7;                               // rejected trial: same direction again from x
+            double step = (slot_of_lane & 1) ? mag : -mag;
+            if (from_x) step = (spec_axis == 0 ? p[0] : p[1]) > 0 ? dq : -dq;
+            const double b0 = from_x ? x[0] : xe[0], b1 = from_x ? x[1] : xe[1];
+            if (slot_of_lane >= 1 && slot_of_lane <= 7) {
+                px0 = spec_axis == 0 ? b0 + step : b0;
+                px1 = spec_axis == 1 ? b1 + step : b1;
             }
         }
-        if (accept) {
-            x[0] = xe[0]; x[1] = xe[1]; f[0] = fn[0]; f[1] = fn[1]; cost = cost_new;
-            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = Jn[r][c];
-            vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2];
+        double res, w[3];
+        bool guard_l = false;
+        pair_eval<CPFIT>(pb, px0, px1, role, dg, res, w, guard_l);
+        dg.evals += 1;
+        STAMP(c_batch)
+        int slot = 0;
+        bool stop = false;
+        // ---- consume: trust-region bookkeeping (trf_no_bounds) for the needed point, and again while the next point
+        //      asked for is one of those evaluated in this pass ---------------------------------------------------
+        for (;;) {
+            double fn[2], Jn[2][2];
+            bool finite;
+            if (it_w && sub == 0) {
+                const int i = first ? 0 : nfev;
+                if (i < MISTI_TRACE_MAX_ITER) { double* r = it_w + ((int64_t)t * MISTI_TRACE_MAX_ITER + i) * 2; r[0] = xe[0]; r[1] = xe[1]; }
+            }
+            const int base = SPEC ? 6 * slot : 0;
+            pair_collect<GROUP>(res, xe, base, fn, Jn, finite);
+            STAMP(c_collect)
+            if (SPEC) { if (__builtin_amdgcn_readlane((int)guard_l, __builtin_amdgcn_readfirstlane(base))) dg.guard = true; }
+            else if (guard_l) dg.guard = true;
+            bool accept = false, done = false;
+            int term = 0;
+            double cost_new = 0.5 * (fn[0] * fn[0] + fn[1] * fn[1]);
+            if (uni<GROUP>(first)) {
+                first = false;
+                nfev = 1;
+                if (uni<GROUP>(!finite)) { status = MISTI_NUMERIC; active = false; stop = true; break; }   // SciPy raises on a non-finite start
+                Delta = sqrt64(xe[0] * xe[0] + xe[1] * xe[1]);
+                if (Delta == 0) Delta = 1.0;
+                alpha = 0.0;
+                accept = true;
+            } else {
+                // straight-line (selects, no branches but the rare alpha rescale): the same expressions as SciPy's
+                ++nfev;
+                const double sn2 = p[0] * p[0] + p[1] * p[1];
+                const double dq = 0.25 * sqrt64(sn2);                            // radius after a poor or non-finite step
+                const double actual = cost - cost_new;
+                const double rq = actual * rcp64(predicted);
+                const double ratio = predicted > 0 ? rq : ((predicted == 0 && actual == 0) ? 1.0 : 0.0);
+                const double Delta_new = ratio < 0.25 ? dq                       // update_tr_radius, common.py:222-245
+                                         : ((ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) ? 2.0 * Delta : Delta);
+                const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;      // check_termination, common.py:705-717
+                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt64(x[0] * x[0] + x[1] * x[1]));
+                const bool x_ok = sn2 < lim * lim;
+                term = !finite ? 0 : ((f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0);
+                if (uni<GROUP>(finite && term == 0 && alpha != 0.0)) alpha *= Delta * rcp64(Delta_new);
+                Delta = !finite ? dq : (term == 0 ? Delta_new : Delta);
+                accept = finite && actual > 0;
+            }
+            // accepted: the trial becomes the current point (selects; g recomputed from whatever (J, f) is current)
+            x[0] = accept ? xe[0] : x[0]; x[1] = accept ? xe[1] : x[1];
+            f[0] = accept ? fn[0] : f[0]; f[1] = accept ? fn[1] : f[1];
+            cost = accept ? cost_new : cost;
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = accept ? Jn[r][c] : J[r][c];
+            vk[0] = accept ? w[0] : vk[0]; vk[1] = accept ? w[1] : vk[1]; vk[2] = accept ? w[2] : vk[2];
+            vk_base = accept ? base : vk_base;           // the lanes whose state vectors belong to the accepted point
             g[0] = J[0][0] * f[0] + J[1][0] * f[1];
             g[1] = J[0][1] * f[0] + J[1][1] * f[1];
-            have_sv = false;
-        }
-        if (term != 0) done = true;
-        else if (accept) {
-            const double g_norm = fmax(fabs(g[0]), fabs(g[1]));
-            if (g_norm < LSQ_GTOL || nfev >= max_nfev || !(g_norm < INFINITY)) done = true;
-        } else if (nfev >= max_nfev) done = true;
-        if (!done) {
-            predicted = next_step(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm);
+            have_sv = have_sv && !accept;
+            STAMP(c_update)
+            if (term != 0) done = true;
+            else if (accept) {
+                const double g_norm = fmax(fabs(g[0]), fabs(g[1]));
+                if (g_norm < LSQ_GTOL || nfev >= max_nfev || !(g_norm < INFINITY)) done = true;
+            } else if (nfev >= max_nfev) done = true;
+            if (uni<GROUP>(done)) {
+                dg.max_nfev = nfev > dg.max_nfev ? nfev : dg.max_nfev;
+                for (int i = 0; i < 3; ++i) { ps.p[0][i] = gbcast<GROUP>(vk[i], vk_base + 0); ps.p[1][i] = gbcast<GROUP>(vk[i], vk_base + 1); }   // :313-317
+                in_solve = false;
+                // OptimizeResult.status: the termination test that fired, 1 = gtol, 0 = evaluation budget (trf.py:452-456,556-558)
+                const int code = term != 0 ? term : ((accept && fmax(fabs(g[0]), fabs(g[1])) < LSQ_GTOL) ? 1 : 0);
+                if (uni<GROUP>(!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3)))) { active = false; stop = true; }   // :312, :346-348
+                break;
+            }
+            predicted = next_step<GROUP>(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm, spec_axis);
             xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
-        } else {
-            dg.max_nfev = nfev > dg.max_nfev ? nfev : dg.max_nfev;
-            for (int i = 0; i < 3; ++i) { ps.p[0][i] = gbcast<GROUP>(vk[i], 0); ps.p[1][i] = gbcast<GROUP>(vk[i], 1); }   // :313-317
-            in_solve = false;
-            // OptimizeResult.status: the termination test that fired, 1 = gtol, 0 = evaluation budget (trf.py:452-456,556-558)
-            const int code = term != 0 ? term : ((accept && fmax(fabs(g[0]), fabs(g[1])) < LSQ_GTOL) ? 1 : 0);
-            if (!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3))) { active = false; break; }   // :312, :346-348
+            STAMP(c_next)
+            if (!SPEC) break;
+            // was the point now needed evaluated in this pass?  (lanes of role 0 carry their slot's point)
+            const unsigned long long hit = __ballot(role == 0 && lane < 6 * SPEC_SLOTS && px0 == xe[0] && px1 == xe[1]);
+            if (hit == 0) break;
+            slot = (__ffsll((long long)hit) - 1) / 6;
+            dg.spec += 1;
         }
+        if (uni<GROUP>(stop)) break;
         STAMP(c_book)
     }
     if (dg.guard) { status = MISTI_NUMERIC; if (!TAIL) t = 0; }       // an overflowing iterate was cut off somewhere
@@ -1177,8 +1252,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
             cb.fail_status[slot] = status;
             double* r = cb.work + slot * 6;
-            r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.squarings; r[4] = dg.max_nfev; r[5] = dg.lm;
+            r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.spec; r[4] = dg.max_nfev; r[5] = dg.lm;
 #ifdef MISTI_STAMP
+            r[0] = (double)c_collect; r[1] = (double)c_update; r[2] = (double)c_next;
             r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
 #endif
         } else {
