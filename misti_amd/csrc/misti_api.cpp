@@ -81,6 +81,7 @@ struct misti_ctx {
     DevBuf st_split, st_params, st_bounds, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     bool trace = false;                 // solver trace (misti_enable_solver_trace)
     DevBuf ws_solver, ws_iters;         // per chain / per candidate solver words; trial points of small batches
+    DevBuf ws_post;                     // default fit: rates after the split per candidate and interval (+ their solver words)
     int64_t trace_n = 0, trace_iter_cap = 0;   // candidates / chains covered by the trace of the last batch
     const int32_t* trace_of = nullptr;  // candidate -> chain of the last batch (device)
     hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
@@ -250,6 +251,13 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.trunk_cap = (int64_t)ntr;
         cb.hint = c->hint_dev;
         cb.bounds = c->dm.n_band > 0 ? d_bounds : nullptr;
+        cb.post_lam = nullptr;
+        cb.post_word = nullptr;
+        if (!(c->dm.flags & MISTI_CPFIT)) {
+            HIP_TRY(c->ws_post.reserve(nc * (numT + 1) * (sizeof(double) + sizeof(int32_t))));
+            cb.post_lam = c->ws_post.as<double>();
+            if (c->trace) cb.post_word = reinterpret_cast<int32_t*>(cb.post_lam + nc * (numT + 1));
+        }
         cb.solver = cb.tail_solver = cb.cand_solver = nullptr;
         cb.iters = nullptr;
         cb.iter_cap = 0;
@@ -463,7 +471,7 @@ int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->ws_solver, &c->ws_iters,
+    for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->ws_solver, &c->ws_iters, &c->ws_post,
                     &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);

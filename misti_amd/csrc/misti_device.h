@@ -70,6 +70,8 @@ struct ChainBufs {
     int32_t* hint;          // host-pinned [3] or NULL: {chains, candidates, batch tag}, written by the last block of discover_kernel
     int32_t seq;            // this batch's tag
     const int32_t* bounds;  // [n][n_band][2] per-candidate (start, end) of every band, or NULL: the model's
+    double* post_lam;       // [n][numT+1] default fit: rates after the split (postsplit_kernel -> spectrum kernel)
+    int32_t* post_word;     // [n][numT+1] their solver words, or NULL (trace off)
     // solver trace (misti_enable_solver_trace), all NULL when off
     int32_t* solver;        // [n][numT] per chain: packed word of interval t (nfev | status << 16 | kind << 20)
     int32_t* tail_solver;   // [n] per candidate with a fractional split: the shortened interval

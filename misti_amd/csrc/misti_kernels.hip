@@ -187,10 +187,16 @@ struct Model {
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
 struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0, spec = 0; };
 // K terms of the Taylor series of exp(M) v for the pair generator, fully unrolled.
-template <int K>
-__device__ __forceinline__ void taylor3(double d0, double d1, double d2, double mu0, double mu1, double v[3], Diag& dg) {
+// INT: also  vint = sum_k (M^k v / k!) / (k + 2)  =  int_0^1 u exp(u M) v du  - the default fit's expected coalescence
+// time needs  M^-1 exp(M) v - M^-2 (exp(M) - I) v  (CorrectLambda.py:99-107), which is exactly that integral: the series
+// has no inverse and no cancellation, where the reference's formula loses ~1/|M|^2 digits, and like the exponential it
+// acts on the vector only, so a decoupled component still sees identical arithmetic in every forward-difference lane
+// (the reference's finite-difference Jacobian has an exactly zero entry there; a 3x3 solve by cofactors does not keep it).
+template <int K, bool INT>
+__device__ __forceinline__ void taylor3(double d0, double d1, double d2, double mu0, double mu1, double v[3], Diag& dg, double vint[3]) {
     double p0 = v[0], p1 = v[1], p2 = v[2];
     double a0 = p0, a1 = p1, a2 = p2;
+    double b0 = 0.5 * p0, b1 = 0.5 * p1, b2 = 0.5 * p2;
     const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
@@ -200,9 +206,11 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
         const double t2 = ((twomu0 * p0 + twomu1 * p1) - d2 * p2) * inv;
         p0 = t0; p1 = t1; p2 = t2;
         a0 += p0; a1 += p1; a2 += p2;
+        if (INT) { const double w2 = 1.0 / (double)(k + 2); b0 = fma(p0, w2, b0); b1 = fma(p1, w2, b1); b2 = fma(p2, w2, b2); }
     }
     dg.terms += K;
     v[0] = a0; v[1] = a1; v[2] = a2;
+    if (INT) { vint[0] = b0; vint[1] = b1; vint[2] = b2; }
 }
 
 // q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
@@ -211,7 +219,11 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
 // with one-directional migration) the forward-difference lanes then perform bit-identical
 // arithmetic on the remaining components, so the Jacobian column is exactly zero - as it is in
 // the reference, whose solver leaves that rate untouched.
-__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], double q, double neg, bool ok, Diag& dg, bool& guard) {
+// INT: with the series path taken, vint receives int_0^1 u exp(u M) v du and have_int is set (see taylor3); the stiff paths
+// leave it unset (there |M| > 1 and the reference's inverse-based formula is well conditioned: the caller uses that).
+template <bool INT = false>
+__device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, double mu1, double v[3], double q, double neg, bool ok, Diag& dg, bool& guard,
+                                          double* vint = nullptr, bool* have_int = nullptr) {
     if (!ok) { l0 = 0.0; l1 = 0.0; }
     double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1;
     double nbmax = q + neg;                                  // >= ||N||_1 (column sums q - l0, q - l1, q)
@@ -255,13 +267,14 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         // reciprocals.  No shift, no exp(); cancellation is bounded by e^2 ulp, and a decoupled
         // component again sees identical arithmetic in every forward-difference lane.
         const double nn = 2.0 * nbmax;                // >= ||M||_1
-        if (nn <= 0.01) taylor3<8>(d0, d1, d2, mu0, mu1, v, dg);
-        else if (nn <= 0.04) taylor3<10>(d0, d1, d2, mu0, mu1, v, dg);
-        else if (nn <= 0.12) taylor3<12>(d0, d1, d2, mu0, mu1, v, dg);
-        else if (nn <= 0.25) taylor3<14>(d0, d1, d2, mu0, mu1, v, dg);
-        else if (nn <= 0.5) taylor3<17>(d0, d1, d2, mu0, mu1, v, dg);
-        else if (nn <= 1.0) taylor3<21>(d0, d1, d2, mu0, mu1, v, dg);
-        else taylor3<27>(d0, d1, d2, mu0, mu1, v, dg);
+        if (nn <= 0.01) taylor3<8, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.04) taylor3<10, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.12) taylor3<12, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.25) taylor3<14, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.5) taylor3<17, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 1.0) taylor3<21, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else taylor3<27, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        if (INT) *have_int = true;
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;
     }
@@ -712,17 +725,23 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
         res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
-        double pn[3];
+        double pn[3], vint[3] = {0.0, 0.0, 0.0};
+        bool have_int = false;
         for (int i = 0; i < 3; ++i) { pn[i] = (k ? pb.P[1][i] : pb.P[0][i]) / sk; w[i] = pn[i]; }
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
-        double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
-        double dd[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
-        double y[3], vec1[3], vec2[3];
-        solve3(M, dd, y);
-        solve3(M, y, vec1);
+        pair_expv<true>(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard, vint, &have_int);
         double pnc = (w[0] + w[1]) + w[2];
-        solve3(M, w, vec2);                         // T = 1 after the stretch
-        double ect = (l0 * (vec2[0] - vec1[0]) + l1 * (vec2[1] - vec1[1])) / (1.0 - pnc);
+        double v0 = vint[0], v1 = vint[1];          // (vec2 - vec1) of the reference, T = 1 after the stretch
+        if (!have_int) {
+            // stiff iterate (|M| > 1): the reference's own formula, M^-1 exp(M) pn - M^-2 (exp(M) - I) pn
+            double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
+            double dd[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
+            double y[3], vec1[3], vec2[3];
+            solve3(M, dd, y);
+            solve3(M, y, vec1);
+            solve3(M, w, vec2);
+            v0 = vec2[0] - vec1[0]; v1 = vec2[1] - vec1[1];
+        }
+        double ect = (l0 * v0 + l1 * v1) / (1.0 - pnc);
         res = ect - (k ? pb.tgt[1] : pb.tgt[0]);
         // the state vector handed on is exp(M) applied to the unnormalised vector
         w[0] *= sk; w[1] *= sk; w[2] *= sk;
@@ -1628,6 +1647,44 @@ void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, int64_t trunk_blocks,
     else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - trunk_blocks, lds);
 }
 
+// Default fit only: the rates after the split (FitSinglePop, CorrectLambda.py:82-92, called at MigrationInference.py:361-364).
+// The weights of the two genomes depend only on the difference of their log-survival at the split (both decay by the
+// same rate afterwards), so every interval is an independent bounded 1-D solve: one THREAD per (candidate, interval).
+// Kept out of the spectrum kernel: the bounded trust-region code needs ~100 registers of its own, which pushed that
+// kernel (128 VGPRs for four waves per SIMD) into scratch.
+__global__ __launch_bounds__(256)
+void postsplit_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split_time, const double* __restrict__ params, ChainBufs cb) {
+    const int rows = m.numT + 1;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n_cand * rows) return;
+    const int64_t cand = gid / rows;
+    const int t = (int)(gid - cand * rows);
+    cb.post_lam[gid] = 1.0;
+    if (cb.post_word) cb.post_word[gid] = 0;
+    Grid G;
+    const double* par = params ? params + cand * m.n_param : nullptr;
+    const int32_t* bb = cb.bounds ? cb.bounds + cand * 2 * m.n_band : nullptr;
+    if (setup_candidate(m, split_time[cand], par, G, bb) != MISTI_OK) return;
+    if (t < G.split || t >= G.numT - 1) return;
+    const int64_t ch = chain_of(cb, cand);
+    const int nfull = (G.ins >= 0) ? G.ins : G.split;
+    if (cb.fail_t[ch] < nfull || (G.ins >= 0 && cb.tail_status[cand] != MISTI_OK)) return;     // no value for this candidate
+    const double T = G.T(t);
+    if (T == 0) return;
+    const double* stt = (G.ins >= 0) ? cb.tail_state + 6 * cand : cb.trace + (ch * (int64_t)(m.numT + 1) + nfull) * 6;   // pair state at the split
+    const double nc0 = (stt[0] + stt[2]) + stt[4], nc1 = (stt[1] + stt[3]) + stt[5];     // :353-354 (a probability used as a log)
+    const double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
+    // FitSinglePop :88-92 with P0 = [[exp(nc0),0,0],[exp(nc1),0,0]] (:361)
+    const double pa = exp(nc0), pb = exp(nc1);
+    const double w0 = pa / (pa + pb), w1 = pb / (pa + pb);
+    const double Te = w0 * ect_one_pop(lh0, T) + w1 * ect_one_pop(lh1, T);
+    double x[1] = {w0 * lh0 + w1 * lh1};
+    auto resid = [&](const double l[1], double f[1]) { f[0] = ect_one_pop(l[0], T) - Te; };
+    const int32_t word = trf_bounded<1>(resid, x, 0.01 * fmin(lh0, lh1));
+    cb.post_lam[gid] = x[0];
+    if (cb.post_word) cb.post_word[gid] = word;
+}
+
 // Kernel 2: post-split rates (:355-376), Smooth (:380-405) and the expected joint spectrum
 // (JAFSpectrum, :467-540).  One wavefront per candidate; lane = interval in the prologue,
 // lane = state of the 44-state chain afterwards.
@@ -1768,14 +1825,9 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                         lam = -log(pnc) / T;
                         word = solver_word(0, 0, 1);
                     } else {
-                        // FitSinglePop :88-92 with P0 = [[exp(nc0),0,0],[exp(nc1),0,0]] (:361)
-                        double pa = exp(nc0), pb = exp(nc1);
-                        double w0 = pa / (pa + pb), w1 = pb / (pa + pb);
-                        double Te = w0 * ect_one_pop(lh0, T) + w1 * ect_one_pop(lh1, T);
-                        double x[1] = {w0 * lh0 + w1 * lh1};
-                        auto resid = [&](const double l[1], double f[1]) { f[0] = ect_one_pop(l[0], T) - Te; };
-                        word = trf_bounded<1>(resid, x, 0.01 * fmin(lh0, lh1));
-                        lam = x[0];
+                        // FitSinglePop (default fit): solved by postsplit_kernel, one thread per interval
+                        lam = cb.post_lam[cand * lc_rows + t];
+                        word = cb.post_word ? cb.post_word[cand * lc_rows + t] : 0;
                     }
                 }
                 lcb[2 * t] = lam; lcb[2 * t + 1] = lam;
@@ -2028,7 +2080,7 @@ hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t
 
 // ------------------------------------------------------- replicate epilogue --
 // llh_const of SetJAFS (MigrationInference.py:217-227): one thread per replicate (misti_llk_dev).
-__global__ void llh_const_kernel(int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
+__global__ __launch_bounds__(256) void llh_const_kernel(int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
     int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rep) return;
     consts[r] = llh_const_of(jsfs + r * 8, unfolded);
@@ -2181,6 +2233,10 @@ hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* ord
     const bool cp = m.flags & MISTI_CPFIT;
     const int cpw = correct_cands_per_wave(n_cand);              // tails: one item per candidate
     MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream)
+    if (!cp) {
+        const int64_t threads = n_cand * (int64_t)(m.numT + 1);
+        hipLaunchKernelGGL(postsplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, m, n_cand, split, params, cb);
+    }
     const int n_inline = (n_rep > 0 && n_rep <= LLK_INLINE_MAX) ? (int)n_rep : 0;
     dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
     if (cp)
