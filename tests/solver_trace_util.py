@@ -44,7 +44,7 @@ def compare_case(case, ref_trace, rel_iter=1e-6):
         kind = int(tr["kind"][0, t])
         ref = (sv["nfev"], sv["status"])
         same = hip == ref and kind == KIND_OF_SITE[sv["site"]]
-        it_diff, rel_here = None, 0.0
+        it_diff, rel_here, rel_at = None, 0.0, None
         if kind == 3 and sv["site"].startswith("two_pop") and t != ins:
             row = t if ins is None or t < ins else t - 1   # iterate rows are intervals of the shared grid
             dev = tr["iterates"][row]
@@ -54,7 +54,7 @@ def compare_case(case, ref_trace, rel_iter=1e-6):
                     break
                 rel = float(np.max(np.abs(dev[i] - np.array(x)) / np.maximum(np.abs(np.array(x)), 1e-300)))
                 if rel > rel_iter and it_diff is None:
-                    it_diff = i
+                    it_diff, rel_at = i, rel
                 if it_diff is None:
                     rel_here = max(rel_here, rel)
         if first is None:
@@ -62,5 +62,5 @@ def compare_case(case, ref_trace, rel_iter=1e-6):
         if same and it_diff is None:
             n_equal += 1
         elif first is None:
-            first = {"t": t, "site": sv["site"], "ref": ref, "hip": hip, "iter": it_diff}
+            first = {"t": t, "site": sv["site"], "ref": ref, "hip": hip, "iter": it_diff, "rel_at_iter": rel_at}
     return {"llh": llh, "n_solves": len(ref_trace["solves"]), "n_equal": n_equal, "first_diff": first, "max_rel_before": max_rel}

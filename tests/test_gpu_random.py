@@ -41,34 +41,45 @@ def random_case(rng):
 
 
 def test_random_models_against_oracle():
+    """The contract of tests/parity.py per model: 1e-9 (+ rounding floor), else within 10 x the oracle's own spread under
+    8 perturbations of 2^-48 of ITS inputs, computed here for exactly the models that need it."""
+    from parity import SELF_FACTOR, perturbed
     from misti_amd.engine import Engine
     from oracle.batch import oracle_eval
     rng = np.random.default_rng(20240607)
-    n_checked = n_regular = 0
-    worst = 0.0
+    n_checked = n_tight = n_self = 0
+    outside = []
     for _ in range(120):
         c = random_case(rng)
         with Engine(c["times"], c["lh"], c["bands"], c["pulses"], n_param=c["P"], sample_date=c["sd"], **c["flags"]) as e:
             r = e.evaluate([c["split"]], [c["params"]] if c["P"] else None, [c["sfs"]])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            o_llk, o_jafs, o_st, run = oracle_eval(c["times"], c["lh"], c["bands"], c["pulses"], c["flags"], c["sd"], c["split"],
-                                                   c["params"], [c["sfs"]])
+
+        def oracle(times, lh):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return oracle_eval(times, lh, c["bands"], c["pulses"], c["flags"], c["sd"], c["split"], c["params"], [c["sfs"]])
+        o_llk, o_jafs, o_st, run = oracle(c["times"], c["lh"])
         n_checked += 1
-        # default fit with anything that mixes the pair states (band or pulse): reference-indeterminate
-        default_mig = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
         if o_st != 0 or r.status[0] != 0:
-            # failure statuses must agree unless the reference is in its noise-driven regime
-            if not (run >= 5.0 or default_mig):
-                assert o_st == r.status[0], (c, o_st, r.status[0])
+            if (o_st != 0) != (r.status[0] != 0):
+                # a failure against a value: only where the oracle itself flips under perturbation
+                fails = [oracle(*perturbed(c["times"], c["lh"], k))[2] != 0 for k in range(8)]
+                assert (o_st != 0 and not all(fails)) or (o_st == 0 and any(fails)), (c, o_st, r.status[0])
             continue
         err = abs(r.llk[0, 0] - o_llk[0])
-        if run < 5.0 and not default_mig:
-            n_regular += 1
-            tol = llk_tol(o_llk[0], c["sfs"], o_jafs, c["flags"]["unfolded"])
-            worst = max(worst, err / abs(o_llk[0]))
-            assert err <= 10 * tol, (c, r.llk[0, 0], o_llk[0], err, tol)
-            np.testing.assert_allclose(r.jafs[0], o_jafs, rtol=1e-8)
+        if err <= llk_tol(o_llk[0], c["sfs"], o_jafs, c["flags"]["unfolded"]):
+            n_tight += 1
+            np.testing.assert_allclose(r.jafs[0], o_jafs, rtol=1e-7)
+            continue
+        vals = [oracle(*perturbed(c["times"], c["lh"], k)) for k in range(8)]
+        fin = [v[0][0] for v in vals if v[2] == 0]
+        spread = max(abs(v - o_llk[0]) for v in fin) if fin else 0.0
+        if err <= SELF_FACTOR * spread:
+            n_self += 1
         else:
-            assert err <= 2e-2 * abs(o_llk[0]), (c, r.llk[0, 0], o_llk[0])
-    assert n_regular >= 60, (n_checked, n_regular)
+            outside.append((err / abs(o_llk[0]), spread / abs(o_llk[0]), run, c["flags"]))
+    assert n_tight >= 60, (n_checked, n_tight, n_self)
+    # a stop/continue flip the eight perturbed runs did not sample: rare, and only in the noise-driven regimes
+    assert len(outside) <= 2, outside
+    for rel, spread, run, flags in outside:
+        assert rel <= 2e-2 and (run >= 5.0 or not flags["cpfit"]), outside
