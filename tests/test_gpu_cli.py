@@ -78,3 +78,73 @@ def test_optimised_band_and_grid(tmp_path):
     assert m, text[-800:]
     mean, lo, hi = (float(v) for v in m.groups())
     assert 18 <= lo <= mean <= hi <= 22
+
+
+def _tokens_match(ours, theirs, rtol):
+    """Same text structure; numeric tokens agree to rtol, everything else byte for byte."""
+    a, b = ours.replace("\t", " \t ").split(" "), theirs.replace("\t", " \t ").split(" ")
+    assert len(a) == len(b), (ours, theirs)
+    for x, y in zip(a, b):
+        try:
+            fy = float(y)
+        except ValueError:
+            assert x == y, (ours, theirs)
+            continue
+        fx = float(x)
+        assert fx == pytest.approx(fy, rel=rtol, abs=1e-300), (x, y, ours, theirs)
+
+
+def test_cli_against_reference_runs(tmp_path):
+    """MiSTI.py itself was run on these files (tests/golden/make_golden.py, one OS process per run): the machine-read
+    result line (MiSTI.py:240, what the test.bs scripts grep) and the -o file (migrationIO.OutputMigration :346-375)
+    must come out the same - structure byte for byte, numbers to the likelihood tolerance."""
+    import json
+    from conftest import GOLDEN
+    fx = json.load(open(os.path.join(GOLDEN, "golden_host.json")))["cli"]
+    for name, key in (("g1.psmc", "psmc1"), ("g2.psmc", "psmc2"), ("data.sfs", "jsfs"), ("setunits.txt", "units")):
+        (tmp_path / name).write_text(fx[key])
+    for run in fx["runs"]:
+        res = tmp_path / "res.mi"
+        if res.exists():
+            res.unlink()
+        from misti_amd.engine import MigrationInference as MIc
+        MIc.COUNT_LLH = MIc.CORRECTION_CALLED = MIc.CORRECTION_FAILED = 0     # per-process counters in the reference (one process per run there)
+        rc, text = run_cli(["g1.psmc", "g2.psmc", "data.sfs"] + run["args"] + ["-wd", str(tmp_path), "--funits", str(tmp_path / "setunits.txt")])
+        assert rc == 0
+        line = [l for l in text.splitlines() if l.startswith("bs_id =")]
+        assert len(line) == 1, text[-800:]
+        _tokens_match(line[0], run["result_line"], 1e-9)
+        # the lines around it that scripts may rely on
+        for must in ("Reading from files:", "Parameter estimates:", "Total number of likelihood function calls is 1",
+                     "Lambda correction called 1 times.", "Lambda correction failed 0 times."):
+            assert must in text and must in run["stdout"], must
+        if run["out_file"] is None:
+            assert not res.exists()                       # -o is honoured with -bs 0 only (MiSTI.py:248-249)
+            continue
+        ours, theirs = res.read_text().splitlines(), run["out_file"].splitlines()
+        assert len(ours) == len(theirs)
+        for a, b in zip(ours, theirs):
+            assert a.split("\t")[0] == b.split("\t")[0]
+            _tokens_match(a, b, 1e-6 if a.startswith("RS") else 1e-9)
+
+
+def test_result_writer_on_the_engine_matches_the_reference_text():
+    """OutputMigration for the anchors A3 (optimised bands, unfolded), A6 (ancient sample) and A7 (fractional split):
+    io.format_migration on the GPU-backed mirror against the reference's own text."""
+    import json
+    from conftest import GOLDEN
+    from misti_amd import io as mio
+    from misti_amd.engine import MigrationInference
+    for c in json.load(open(os.path.join(GOLDEN, "golden_host.json")))["writer"]:
+        i = c["in"]
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            m = MigrationInference(list(i["times"]), [list(x) for x in i["lambdas"]], list(i["sfs"]), i["split"], [list(x) for x in i["mi"]],
+                                   [list(x) for x in i["pu"]], thrh=i["thrh"], **i["kw"])
+            llh = m.JAFSLikelihood(list(i["params"]))
+        text = mio.format_migration(m, llh, i["scaleTime"], i["scaleEPS"])
+        ours, theirs = text.splitlines(), c["text"].splitlines()
+        theirs = [l for l in theirs if l != ""]
+        assert len(ours) == len(theirs), c["name"]
+        for a, b in zip(ours, theirs):
+            _tokens_match(a, b, 1e-6 if a.startswith("RS") else 1e-9)

@@ -65,7 +65,11 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for a, b in (("bench.json", "_bench.json"), ("bench_serial.json", "_bench_serial.json")):
+    for a, b in (("bench.json", "_bench.json"), ("bench_serial.json", "_bench_serial.json"), ("bench_config3.json", "_bench_config3.json"),
+                 ("bench_config4.json", "_bench_config4.json"), ("bench_config5.json", "_bench_config5.json"),
+                 ("bench_config3_search.json", "_bench_config3_search.json"), ("bench_dist_weak.json", "_bench_dist_weak_1rank.json"),
+                 ("bench_dist_strong_config4.json", "_bench_dist_strong_config4_1rank.json"),
+                 ("bench_dist_strong_config5.json", "_bench_dist_strong_config5_1rank.json")):
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p):
             line = [l for l in open(p) if l.startswith("{")][-1]
