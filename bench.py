@@ -134,13 +134,16 @@ def algorithmic_bytes(w, n_rep, idx=None):
     return {"correct": correct, "spectrum": spectrum, "llk": n * (60 + 8 * n_rep), "n_chains": len(chains)}
 
 
-def cpu_baseline_child(w, idx, cores):
-    """The oracle on `idx` in a freshly started child process (it forks its worker pool there: no fork after this
-    process has initialised HIP / torch / RCCL - ADVICE r1).  Returns (llk[m][R], status[m], runaway[m], wall)."""
+def cpu_baseline_child(w, idx, cores, idx_compiled):
+    """The CPU baselines in a freshly started child process (the NumPy oracle forks its worker pool there: no fork after
+    this process has initialised HIP / torch / RCCL - ADVICE r1; the compiled baseline runs its OpenMP threads there too).
+    Returns the child's result arrays: llk, status, runaway, wall of the NumPy oracle on `idx`; c_* of the compiled
+    baseline (oracle/cpu/misti_cpu.cpp) on `idx_compiled`."""
     with tempfile.TemporaryDirectory() as tmp:
         src, dst = os.path.join(tmp, "in.npz"), os.path.join(tmp, "out.npz")
         np.savez(src, times=np.asarray(w.times, dtype=float), lh=np.asarray(w.lh, dtype=float), split=w.split_time,
                  params=w.params if w.params is not None else np.zeros((0, 0)), jsfs=w.jsfs, idx=np.asarray(idx),
+                 idx_compiled=np.asarray(idx_compiled),
                  meta=json.dumps({"bands": w.bands, "pulses": w.pulses, "flags": w.flags, "sample_date": w.sample_date,
                                   "n_param": w.n_param, "cores": cores}))
         env = dict(os.environ)
@@ -149,7 +152,7 @@ def cpu_baseline_child(w, idx, cores):
         if r.returncode != 0:
             raise RuntimeError("cpu_baseline child failed (%d)" % r.returncode)
         d = np.load(dst)
-        return d["llk"], d["status"], d["runaway"], float(d["wall"])
+        return {k: d[k] for k in d.files}
 
 
 def main():
@@ -375,10 +378,27 @@ def main():
             per_core = 12.0                                                  # evals/s/core, order of magnitude (measured ~18)
             m = int(max(cores, min(n, a.cpu_seconds * per_core * cores)))
             idx = np.linspace(0, n - 1, m).astype(np.int64)
-            o_llk, o_status, o_run, wall = cpu_baseline_child(w, mine[idx], cores)
-            out["cpu_baseline"] = {"value": len(idx) * R / wall, "unit": "llk evals/s", "cores": cores, "kind": "port",
-                                   "sample": "%d of the %d candidates (evenly spaced) x %d replicate(s), NumPy/SciPy oracle, one process per core "
-                                             "(forked by a child process that never touched the GPU), %.1f s wall" % (len(idx), n, R, wall)}
+            # the compiled baseline is ~50 x faster per core: a larger sample (the whole grid where that fits the budget)
+            mc = int(max(cores, min(n, a.cpu_seconds * 90.0 * cores)))
+            idx_c = np.linspace(0, n - 1, mc).astype(np.int64)
+            res = cpu_baseline_child(w, mine[idx], cores, mine[idx_c])
+            o_llk, o_status, o_run, wall = res["llk"], res["status"], res["runaway"], float(res["wall"])
+            c_wall = float(res["c_wall"])
+            out["cpu_baseline"] = {"value": len(idx_c) * R / c_wall, "unit": "llk evals/s", "cores": cores, "kind": "port",
+                                   "sample": "%d of the %d candidates (evenly spaced) x %d replicate(s); compiled restatement of the reference's algorithm "
+                                             "(oracle/cpu/misti_cpu.cpp: C++17 + OpenMP, dense Pade expm + LU per interval, SciPy's TRF restated; pinned on "
+                                             "the reference's golden vectors), one candidate per OpenMP task, %.1f s wall" % (len(idx_c), n, R, c_wall)}
+            out["cpu_baseline_numpy"] = {"value": len(idx) * R / wall, "unit": "llk evals/s", "cores": cores, "kind": "port",
+                                         "sample": "%d of the %d candidates (evenly spaced) x %d replicate(s), NumPy/SciPy oracle (the reference's own "
+                                                   "SciPy calls), one process per core (forked by a child process that never touched the GPU), %.1f s wall"
+                                                   % (len(idx), n, R, wall)}
+            cb = (res["c_status"] == 0) & (status[idx_c] == 0)
+            crel = np.abs(llk[idx_c, 0] - res["c_llk"][:, 0]) / np.abs(res["c_llk"][:, 0])
+            creg = cb & (res["c_runaway"] < 5.0)
+            out["parity_vs_compiled_baseline_sample"] = {
+                "n": int(cb.sum()), "status_agree": float((res["c_status"] == status[idx_c]).mean()),
+                "regular": {"n": int(creg.sum()), "max_rel": float(crel[creg].max()) if creg.any() else None,
+                            "frac_within_1e-9": float((crel[creg] <= 1e-9).mean()) if creg.any() else None}}
             # the same sample doubles as an end-to-end parity check of this run
             both = (o_status == 0) & (status[idx] == 0)
             rel = np.abs(llk[idx, 0] - o_llk[:, 0]) / np.abs(o_llk[:, 0])

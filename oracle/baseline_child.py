@@ -25,7 +25,16 @@ def main():
                         sample_date=meta["sample_date"], jsfs=d["jsfs"], split_time=d["split"],
                         params=params if meta["n_param"] else None)
     llk, status, wall = oracle_batch(w, [int(i) for i in d["idx"]], processes=int(meta["cores"]))
-    np.savez(dst, llk=llk, status=status, runaway=oracle_batch.last_runaway, wall=wall)
+    out = dict(llk=llk, status=status, runaway=oracle_batch.last_runaway, wall=wall)
+    if "idx_compiled" in d.files:
+        # the compiled baseline (C++17 + OpenMP, oracle/cpu/misti_cpu.cpp) on its own (larger) sample of the same workload
+        from .cpu_baseline import cpu_eval
+        ic = [int(i) for i in d["idx_compiled"]]
+        c_llk, _, c_status, c_run, c_wall = cpu_eval(w.times, w.lh, w.bands, w.pulses, w.flags, w.sample_date, w.split_time[ic],
+                                                     None if w.params is None else w.params[ic], w.jsfs, int(meta["n_param"]),
+                                                     threads=int(meta["cores"]))
+        out.update(c_llk=c_llk, c_status=c_status, c_runaway=c_run, c_wall=c_wall)
+    np.savez(dst, **out)
 
 
 if __name__ == "__main__":
