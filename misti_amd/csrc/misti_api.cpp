@@ -76,6 +76,8 @@ struct misti_ctx {
     int32_t* hint_host = nullptr;       // pinned, device-visible: {chains, candidates} of the last batch (a launch-shape hint only)
     int32_t* hint_dev = nullptr;
     int32_t batch_seq = 0;
+    int table_cur = 0;                  // which of the two chain-table sets the next batch uses
+    size_t table_clean[2] = {0, 0};     // table size each set is known to be clean for (0: not clean)
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_bounds, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
@@ -226,9 +228,15 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const size_t tsize = misti::chain_table_size(n_cand);
     const size_t ntr = (size_t)misti::trunk_capacity(n_cand);
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
-    const size_t i32_n = 2 + 3 * tsize + 7 * nc + ntr;      // n_chains | table, slot_chain, slot_len | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
+    // chain tables: TWO sets {n_chains[2], table, slot_chain, slot_len} used alternately - a batch clears the other set for its successor
+    const size_t set_n = 2 + 3 * tsize;
+    const size_t i32_n = 2 * set_n + 7 * nc + ntr;          // two table sets | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
-    HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
+    {
+        void* before = c->ws_chain_i32.p;
+        HIP_TRY(c->ws_chain_i32.reserve(i32_n * sizeof(int32_t)));
+        if (c->ws_chain_i32.p != before) c->table_clean[0] = c->table_clean[1] = 0;      // a new allocation: nothing is clean
+    }
     HIP_TRY(c->ws_order.reserve(nc * sizeof(int32_t)));
     if (ntr) HIP_TRY(c->ws_trunk.reserve(ntr * numT * misti::TRUNK_REC * sizeof(double)));
     if (n_rep > 0) HIP_TRY(c->consts.reserve((size_t)n_rep * sizeof(double)));
@@ -241,8 +249,15 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.tail_lc = d; d += nc * 2;
         cb.tail_state = d;
         int32_t* q = c->ws_chain_i32.as<int32_t>();
-        cb.n_chains = q; q += 2;
-        cb.table = q; q += tsize; cb.slot_chain = q; q += tsize; cb.slot_len = q; q += tsize;
+        const int cur = c->table_cur;
+        int32_t* set[2] = {q, q + set_n};
+        q += 2 * set_n;
+        // a set is clean for this batch if the previous batch cleared it for exactly this table size (same layout)
+        if (c->table_clean[cur] != tsize) HIP_TRY(hipMemsetAsync(set[cur], 0, set_n * sizeof(int32_t), c->stream));
+        c->table_clean[cur] = 0;                    // about to be used
+        c->table_clean[cur ^ 1] = 0;                // until the setup launch below is in the stream
+        cb.n_chains = set[cur]; cb.table = set[cur] + 2; cb.slot_chain = cb.table + tsize; cb.slot_len = cb.slot_chain + tsize;
+        cb.z_n_chains = set[cur ^ 1]; cb.z_table = set[cur ^ 1] + 2; cb.z_slot_len = cb.z_table + 2 * tsize;
         cb.slot_of = q; q += nc; cb.of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
         cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc;
         cb.trunk_ok = q;
@@ -281,7 +296,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
             }
         }
     }
-    // Launch shape of kernel 1 depends on the number of chains, which lives on the device: discover_kernel drops
+    // Launch shape of kernel 1 depends on the number of chains, which lives on the device: setup_kernel drops
     // {chains, candidates, batch tag} into pinned memory.  A batch of the same size as the previous one on this
     // context uses that one's count (no waiting; a stale value costs speed only); otherwise the host waits for
     // this batch's own count - bounded, a few microseconds after the launch.
@@ -297,15 +312,17 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cpw = (est >= 0 && est <= 256) ? 1 : misti::correct_cands_per_wave(n_cand);
         follow = misti::trunk_follows(cpw, (int64_t)ntr);
     };
-    // a batch is five launches (six with more than LLK_INLINE_MAX replicates): prepare | discover | chains |
+    // a batch is four launches (+1 for the default fit, +1 with more than LLK_INLINE_MAX replicates): setup | chains |
     // trunks + tails | candidates (+ replicate epilogue).  Few launches matter when many batches are in flight.
     int32_t* d_order = c->ws_order.as<int32_t>();
     double* d_consts = n_rep > 0 ? c->consts.as<double>() : nullptr;
     const bool llk_inline = n_rep > 0 && n_rep <= misti::LLK_INLINE_MAX;
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY_EV(misti::launch_prepare(n_cand, d_split, c->dm.numT, d_order, cb, n_rep, d_jsfs, d_consts, c->unfolded, c->stream), a, b);
-    HIP_TRY_EV(misti::launch_chain_discovery(n_cand, c->dm.n_param, cb.bounds ? c->dm.n_band : 0, d_params, d_split, c->dm.numT, cb, c->stream), a, b);
+    HIP_TRY_EV(misti::launch_setup(n_cand, c->dm.n_param, cb.bounds ? c->dm.n_band : 0, d_params, d_split, c->dm.numT, cb, d_order,
+                                   n_rep, d_jsfs, d_consts, c->unfolded, c->stream), a, b);
+    c->table_clean[c->table_cur ^ 1] = tsize;       // setup_kernel clears the other set (table, slot_len, counters) for this table size
+    c->table_cur ^= 1;
     if (est_chains < 0 && hint && misti::correct_cands_per_wave(n_cand) > 1) {
         const auto t0 = std::chrono::steady_clock::now();
         while (hint[2] != cb.seq && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) std::this_thread::yield();

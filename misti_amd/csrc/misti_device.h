@@ -47,7 +47,10 @@ struct DevModel {
 // parameter vectors share a chain; chains are found by inserting every candidate into an open-addressing
 // table keyed by its parameters (discover_kernel): the first one in a slot owns the chain.
 struct ChainBufs {
-    int32_t* n_chains;      // [2]: chains; blocks of discover_kernel that have finished
+    int32_t* n_chains;      // [2]: chains; candidate blocks of setup_kernel that have finished
+    int32_t* z_n_chains;    // the OTHER set of {n_chains, table, slot_len}: cleared by this batch for the next one
+    int32_t* z_table;
+    int32_t* z_slot_len;
     int32_t* table;         // [tsize] slot -> owner candidate + 1, 0 = empty
     int32_t* slot_chain;    // [tsize] slot -> chain
     int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
@@ -133,9 +136,8 @@ hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
 int64_t trunk_capacity(int64_t n_cand);
 uint32_t chain_table_size(int64_t n_cand);
-hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
-                          int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
-hipError_t launch_chain_discovery(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream);
+hipError_t launch_setup(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, int32_t* order,
+                        int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
 int correct_cands_per_wave(int64_t n_items);
 bool trunk_follows(int cpw_chains, int64_t trunk_cap);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,

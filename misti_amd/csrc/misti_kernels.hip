@@ -1,9 +1,9 @@
 // MI355X (gfx950) kernels of the MiSTI composite-likelihood engine.
 //
-// A batch of candidates (split time, band rates, pulse rates) x bootstrap JSFS replicates is five
+// A batch of candidates (split time, band rates, pulse rates) x bootstrap JSFS replicates is four
 // launches:
-//   prepare_kernel          dispatch order, chain-table reset, llh_const of the replicates
-//   discover_kernel         candidates with identical parameters share a CHAIN (hash table)
+//   setup_kernel            candidates with identical parameters share a CHAIN (hash table); dispatch order; llh_const of the
+//                           replicates; the other (double-buffered) chain table cleared for the next batch
 //   correct_[follow_]kernel lambda-correction of the chains, a resumable state machine per chain;
 //                           with one chain per wave a second wave of the workgroup builds the
 //                           chain's TRUNK (44-state propagation shared by its candidates) behind it
@@ -1974,13 +1974,47 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 
 // Every candidate is inserted into an open-addressing table keyed by the bits of its parameter
-// vector (linear probing; the table was zeroed by prepare_kernel).  The first candidate in a slot
+// vector (linear probing; the table was cleared during the previous batch, see setup_kernel).  The first candidate in a slot
 // owns the chain and draws the chain id; equal hashes are verified against the owner's parameters
 // (read-only input), so a collision costs a probe, never correctness.  Chain ids depend on the
 // order of arrival - they only name buffers; no result depends on them.
+// First launch of a batch, everything that depends on the inputs alone, in ONE kernel (a launch behind a long kernel
+// costs its queue a scheduler round trip, which is what limits the rate with many batches in flight):
+//   blocks [0, cand_blocks)   chain discovery, one thread per candidate; on the way every thread clears a slice of the
+//                             OTHER chain table - the tables are double-buffered, the next batch of this context finds
+//                             its table clean without a launch of its own (nothing of the previous batch is running:
+//                             same stream);
+//   block cand_blocks         dispatch order: candidates sorted by descending split index (counting sort).  Work per
+//                             candidate grows with the number of two-population intervals and the dispatcher hands
+//                             blocks out in index order, so the longest start first.  The order never affects a result;
+//   the blocks after it       llh_const of every replicate.
 __global__ __launch_bounds__(256)
-void discover_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb) {
+void setup_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb,
+                  int cand_blocks, int32_t* __restrict__ order, int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
+    if ((int)blockIdx.x > cand_blocks) {
+        const int64_t r = (int64_t)((int)blockIdx.x - cand_blocks - 1) * blockDim.x + threadIdx.x;
+        if (r < n_rep) consts[r] = llh_const_of(jsfs + r * 8, unfolded);
+        return;
+    }
+    if ((int)blockIdx.x == cand_blocks) {
+        __shared__ int hist[MISTI_MAX_NUMT + 4];
+        const int nb = numT + 3;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
+        __syncthreads();
+        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
+        return;
+    }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    {   // clear the other table for the next batch
+        const int64_t tsize = (int64_t)cb.tmask + 1, nthr = (int64_t)cand_blocks * blockDim.x;
+        for (int64_t k = i; k < tsize; k += nthr) { cb.z_table[k] = 0; cb.z_slot_len[k] = 0; }
+        if (i == 0) { cb.z_n_chains[0] = 0; cb.z_n_chains[1] = 0; }
+    }
     if (i < n) {
         // the key: the parameter bits and, with per-candidate band bounds, the (start, end) pairs as given (end == -1
         // stays symbolic: members of a chain may differ in their split, never in where a band starts or ends)
@@ -1989,14 +2023,14 @@ void discover_kernel(int64_t n, int P, int NB2, const double* __restrict__ param
         const int32_t* ab = cb.bounds ? cb.bounds + i * NB2 : nullptr;
         for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
         if (ab) for (int k = 0; k < NB2; ++k) h = mix64(h ^ (uint64_t)(uint32_t)ab[k]);
-        uint32_t s = (uint32_t)(h >> 20) & cb.tmask;
+        uint32_t sl = (uint32_t)(h >> 20) & cb.tmask;
         for (;;) {
-            const int prev = atomicCAS(&cb.table[s], 0, (int)i + 1);
+            const int prev = atomicCAS(&cb.table[sl], 0, (int)i + 1);
             if (prev == 0) {
                 const int ch = atomicAdd(cb.n_chains, 1);
-                cb.chain_slot[ch] = (int32_t)s;
+                cb.chain_slot[ch] = (int32_t)sl;
                 cb.rep[ch] = (int32_t)i;
-                cb.slot_chain[s] = ch;
+                cb.slot_chain[sl] = ch;
                 break;
             }
             const double* b = params + (int64_t)(prev - 1) * P;
@@ -2004,21 +2038,21 @@ void discover_kernel(int64_t n, int P, int NB2, const double* __restrict__ param
             for (int k = 0; k < P; ++k) if (__double_as_longlong(a[k]) != __double_as_longlong(b[k])) same = false;
             if (ab) { const int32_t* bbp = cb.bounds + (int64_t)(prev - 1) * NB2; for (int k = 0; k < NB2; ++k) if (ab[k] != bbp[k]) same = false; }
             if (same) break;
-            s = (s + 1) & cb.tmask;
+            sl = (sl + 1) & cb.tmask;
         }
-        cb.slot_of[i] = (int32_t)s;
+        cb.slot_of[i] = (int32_t)sl;
         const double st = split_time[i];
         int need = 0;
         if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
-        atomicMax(&cb.slot_len[s], need);
+        atomicMax(&cb.slot_len[sl], need);
     }
-    // the last block to finish tells the host how many chains there are: pinned memory, {chains, candidates, batch tag};
+    // the last candidate block to finish tells the host how many chains there are: pinned memory, {chains, candidates, batch tag};
     // the host uses it for the launch shape of kernel 1 (this batch if it cares to wait a few microseconds, else the next)
     if (cb.hint) {
         __syncthreads();
         if (threadIdx.x == 0) {
             __threadfence();
-            if (atomicAdd(&cb.n_chains[1], 1) == (int)gridDim.x - 1) {
+            if (atomicAdd(&cb.n_chains[1], 1) == cand_blocks - 1) {
                 cb.hint[0] = atomicAdd(cb.n_chains, 0);
                 cb.hint[1] = (int32_t)n;
                 __threadfence_system();
@@ -2034,47 +2068,13 @@ uint32_t chain_table_size(int64_t n_cand) {
     return t;
 }
 
-hipError_t launch_chain_discovery(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, hipStream_t stream) {
+hipError_t launch_setup(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, int32_t* order,
+                        int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(discover_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, P, 2 * n_band, params, split, numT, cb);
-    return hipGetLastError();
-}
-
-// First launch of a batch, everything that depends on the inputs alone:
-//  * block 0: dispatch order - candidates sorted by descending split index (counting sort).  Work
-//    per candidate grows with the number of two-population intervals and the dispatcher hands
-//    blocks out in index order, so the longest start first.  The order never affects a result;
-//  * the other blocks: zero the chain table, llh_const of every replicate.
-__global__ __launch_bounds__(256)
-void prepare_kernel(int64_t n_cand, const double* __restrict__ split_time, int numT, int32_t* __restrict__ order, ChainBufs cb,
-                    int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
-    if (blockIdx.x == 0) {
-        __shared__ int hist[MISTI_MAX_NUMT + 4];
-        const int nb = numT + 3;
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
-        for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
-        __syncthreads();
-        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } cb.n_chains[0] = 0; cb.n_chains[1] = 0; }
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
-        if (gridDim.x > 1) return;
-    }
-    const int64_t nthr = (int64_t)(gridDim.x > 1 ? gridDim.x - 1 : 1) * blockDim.x;
-    const int64_t tid = (int64_t)(gridDim.x > 1 ? blockIdx.x - 1 : 0) * blockDim.x + threadIdx.x;
-    const int64_t tsize = (int64_t)cb.tmask + 1;
-    for (int64_t i = tid; i < tsize; i += nthr) { cb.table[i] = 0; cb.slot_len[i] = 0; }
-    for (int64_t r = tid; r < n_rep; r += nthr) consts[r] = llh_const_of(jsfs + r * 8, unfolded);
-}
-
-hipError_t launch_prepare(int64_t n_cand, const double* split, int numT, int32_t* order, const ChainBufs& cb,
-                          int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream) {
-    if (n_cand <= 0) return hipSuccess;
-    const int64_t items = ((int64_t)cb.tmask + 1 > n_rep ? (int64_t)cb.tmask + 1 : n_rep);
-    int64_t nb = 1 + (items + 256 * 8 - 1) / (256 * 8);
-    if (nb > 257) nb = 257;
-    hipLaunchKernelGGL(prepare_kernel, dim3((unsigned)nb), dim3(256), 0, stream, n_cand, split, numT, order, cb, n_rep, jsfs, consts, unfolded);
+    const int cand_blocks = (int)((n + 255) / 256);
+    const int rep_blocks = (int)((n_rep + 255) / 256);
+    hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(cand_blocks + 1 + rep_blocks)), dim3(256), 0, stream, n, P, 2 * n_band, params, split, numT, cb,
+                       cand_blocks, order, n_rep, jsfs, consts, unfolded);
     return hipGetLastError();
 }
 
