@@ -36,7 +36,8 @@ def stats_csv(src_dir, dst):
     if not files:
         print("no kernel stats under", src_dir)
         return
-    rows = list(csv.reader(open(files[0])))
+    files.sort(key=os.path.getmtime)          # gpurun_out/ accumulates: the newest run of this tag
+    rows = list(csv.reader(open(files[-1])))
     with open(dst, "w", newline="") as f:
         wr = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
         wr.writerow(rows[0])
@@ -49,7 +50,8 @@ def stats_csv(src_dir, dst):
 def pmc_last(src_dir):
     """{kernel: {counter: value of the kernel's last launch}} - the last launches are the timed bench batches."""
     out, seen = {}, {}
-    for fn in glob.glob(os.path.join(src_dir, "*", "*_counter_collection.csv")):
+    found = sorted(glob.glob(os.path.join(src_dir, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    for fn in found[-1:]:                     # the newest run of this tag only
         for r in csv.DictReader(open(fn)):
             k = short(r["Kernel_Name"])
             key = (k, r["Counter_Name"])
