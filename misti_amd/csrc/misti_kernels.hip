@@ -748,21 +748,59 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
     }
 }
 
-// Residuals and forward-difference Jacobian at the point xe from the six lanes base .. base + 5 that evaluated it.
-template <int GROUP>
-__device__ __forceinline__ void pair_collect(double res, const double xe[2], int base, double f[2], double J[2][2], bool& finite) {
-    const double x0 = xe[0], x1 = xe[1];
+// Residuals and forward-difference Jacobian at a point from the six residuals evaluated there (base point, first rate
+// stepped, second rate stepped; both genomes).
+__device__ __forceinline__ void collect_core(double x0, double x1, double fb0, double fb1, double fa0, double fa1, double fc0, double fc1,
+                                             double f[2], double J[2][2], bool& finite) {
     const double h0 = fd_step(x0), h1 = fd_step(x1);
     const double xa = x0 + h0, xb = x1 + h1;
     const double dx0 = xa - x0, dx1 = xb - x1;      // recomputed as exactly representable (_numdiff.py)
-    const double fb0 = gbcast<GROUP>(res, base + 0), fb1 = gbcast<GROUP>(res, base + 1);
-    const double fa0 = gbcast<GROUP>(res, base + 2), fa1 = gbcast<GROUP>(res, base + 3);
-    const double fc0 = gbcast<GROUP>(res, base + 4), fc1 = gbcast<GROUP>(res, base + 5);
     const double r0 = rcp64(dx0), r1 = rcp64(dx1);
     f[0] = fb0; f[1] = fb1;
     J[0][0] = (fa0 - fb0) * r0; J[1][0] = (fa1 - fb1) * r0;
     J[0][1] = (fc0 - fb0) * r1; J[1][1] = (fc1 - fb1) * r1;
     finite = isfinite(fb0) && isfinite(fb1);
+}
+// ... at the point xe from the six lanes base .. base + 5 that evaluated it (wave- or group-uniform result)
+template <int GROUP>
+__device__ __forceinline__ void pair_collect(double res, const double xe[2], int base, double f[2], double J[2][2], bool& finite) {
+    const double fb0 = gbcast<GROUP>(res, base + 0), fb1 = gbcast<GROUP>(res, base + 1);
+    const double fa0 = gbcast<GROUP>(res, base + 2), fa1 = gbcast<GROUP>(res, base + 3);
+    const double fc0 = gbcast<GROUP>(res, base + 4), fc1 = gbcast<GROUP>(res, base + 5);
+    collect_core(xe[0], xe[1], fb0, fb1, fa0, fa1, fc0, fc1, f, J, finite);
+}
+// ... in every slot at once: each lane gets the result of ITS slot (lanes sbase .. sbase + 5) at its slot's point
+__device__ __forceinline__ void slot_collect(double res, double x0, double x1, int sbase, double f[2], double J[2][2], bool& finite) {
+    const double fb0 = __shfl(res, sbase + 0, 64), fb1 = __shfl(res, sbase + 1, 64);
+    const double fa0 = __shfl(res, sbase + 2, 64), fa1 = __shfl(res, sbase + 3, 64);
+    const double fc0 = __shfl(res, sbase + 4, 64), fc1 = __shfl(res, sbase + 5, 64);
+    collect_core(x0, x1, fb0, fb1, fa0, fa1, fc0, fc1, f, J, finite);
+}
+
+// Trust-region bookkeeping of one evaluated trial of trf_no_bounds (trf.py:488-521; update_tr_radius,
+// common.py:222-245; check_termination, common.py:705-717).  Straight-line (selects, no branches): run with
+// wave-uniform operands by the serial consume loop and with one hypothesis per slot by the tree consume of
+// correct_body - the same expressions, so the same bits.
+__device__ __forceinline__ void tr_update(bool finite, const double p[2], const double x[2], double cost, double cost_new, double predicted,
+                                          double& Delta, double& dq, int& term, bool& accept) {
+    const double sn2 = p[0] * p[0] + p[1] * p[1];
+    dq = 0.25 * sqrt64(sn2);                                         // radius after a poor or non-finite step
+    const double actual = cost - cost_new;
+    const double rq = actual * rcp64(predicted);
+    const double ratio = predicted > 0 ? rq : ((predicted == 0 && actual == 0) ? 1.0 : 0.0);
+    const double Delta_new = ratio < 0.25 ? dq                       // update_tr_radius
+                             : ((ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) ? 2.0 * Delta : Delta);
+    const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;      // check_termination
+    const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt64(x[0] * x[0] + x[1] * x[1]));
+    const bool x_ok = sn2 < lim * lim;
+    term = !finite ? 0 : ((f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0);
+    Delta = !finite ? dq : (term == 0 ? Delta_new : Delta);
+    accept = finite && actual > 0;
+}
+// predicted reduction -(0.5 |J p|^2 + p . g) of a step (evaluate_quadratic, common.py:276)
+__device__ __forceinline__ double predicted_of(const double J[2][2], const double p[2], const double g[2]) {
+    const double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
+    return -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
 }
 
 // Next trial step of trf_no_bounds (trf.py:469-486): Gauss-Newton step when the Jacobian has
@@ -799,8 +837,7 @@ __device__ __forceinline__ double next_step(const double J[2][2], const double f
         solve_tr(sv, 2, Delta, alpha, p);
         lm += 1;
     }
-    const double Js0 = J[0][0] * p[0] + J[0][1] * p[1], Js1 = J[1][0] * p[0] + J[1][1] * p[1];
-    return -(0.5 * (Js0 * Js0 + Js1 * Js1) + (p[0] * g[0] + p[1] * g[1]));
+    return predicted_of(J, p, g);
 }
 
 // ------------------------------------------------ two-population correction --
@@ -1026,7 +1063,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 #define MISTI_SPEC 1
 #endif
     constexpr bool SPEC = MISTI_SPEC && (GROUP == 64) && !TAIL;
-    constexpr int SPEC_SLOTS = 8;
+    constexpr int SPEC_SLOTS = 10;
     const int slot_of_lane = SPEC ? (lane < 6 * SPEC_SLOTS ? lane / 6 : 0) : 0;
     const int role = SPEC ? (lane < 6 * SPEC_SLOTS ? lane % 6 : (lane - 6 * SPEC_SLOTS) % 6) : sub;   // lanes beyond the slots repeat slot 0
     int spec_axis = -1;        // >= 0: the solver is in the exact rank-one regime and moves along this axis
@@ -1053,7 +1090,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     };
 
 #ifdef MISTI_STAMP
-    long long c_adv = 0, c_batch = 0, c_book = 0, c_t0 = 0, c_collect = 0, c_update = 0, c_next = 0;
+    long long c_adv = 0, c_batch = 0, c_book = 0, c_t0 = 0, c_collect = 0, c_update = 0, c_next = 0, c_tree = 0;
 #define STAMP(acc) { long long now_ = clock64(); acc += now_ - c_t0; c_t0 = now_; }
 #else
 #define STAMP(acc)
@@ -1155,27 +1192,39 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             if (uni<GROUP>(!in_solve)) { active = false; break; }  // reached the split, or failed
         }
         STAMP(c_adv)
-        // ---- one residual batch: the point the solver needs in slot 0, guesses of its successor in the other slots ----
+        // ---- one residual batch: the point the solver needs in slot 0, guesses of its successors in the other slots ----
         // One chain per wave leaves 58 of 64 lanes idle during an evaluation.  In the exact rank-one regime (a rate
         // decoupled after a runaway: its Jacobian column is exactly zero and the solver moves along the other axis by
-        // +-Delta, see next_step) the point after the trial xe is one of a handful - radius doubled, kept or quartered,
-        // either sign, from xe if the trial is accepted or from x if it is rejected - all computable before the trial's
-        // residual is known.  They are evaluated in the idle lanes (slot s = lanes 6 s .. 6 s + 5) by the same pure
-        // function of the point, so when the bookkeeping then asks for one of them its six residuals are already there:
-        // two solver steps per pass instead of one, bit for bit the same iteration.  A guess never consumed costs nothing.
+        // +-Delta, see next_step) the iteration is a walk on a line whose next points are computable before the trial's
+        // residual is known: the trial is accepted and the radius doubled (next point xe +- 2 Delta) or it is rejected
+        // and the radius quartered (next point x + sign Delta/4) - 98 % of the steps of the reference's traces
+        // (tests/golden/golden_traces.json.gz) - and the same again one level down.  The tree of those successors
+        //        slot 0  the trial                     1, 2  0 accepted, doubled, then + / -        3  0 rejected
+        //        4, 5    1 / 2 rejected                6, 7  3 accepted, doubled, then + / -        8  3 rejected
+        // is evaluated in the idle lanes (slot s = lanes 6 s .. 6 s + 5) by the same pure function of the point, and the
+        // bookkeeping of all of them is then done at once, one hypothesis per slot (tree consume below): up to three
+        // solver steps per pass, bit for bit the same iteration.  A guess never consumed costs nothing.
         double px0 = xe[0], px1 = xe[1];
-        if (SPEC && spec_axis >= 0 && !first) {
-            const double sn2 = p[0] * p[0] + p[1] * p[1];
-            const double dq = 0.25 * sqrt64(sn2);                               // the radius after a poor step (update_tr_radius)
-            const double mag = slot_of_lane <= 2 ? 2.0 * Delta : (slot_of_lane <= 4 ? Delta : dq);
-            const bool from_x = slot_of_lane == 7;                               // rejected trial: same direction again from x
-            double step = (slot_of_lane & 1) ? mag : -mag;
-            if (from_x) step = (spec_axis == 0 ? p[0] : p[1]) > 0 ? dq : -dq;
-            const double b0 = from_x ? x[0] : xe[0], b1 = from_x ? x[1] : xe[1];
-            if (slot_of_lane >= 1 && slot_of_lane <= 7) {
-                px0 = spec_axis == 0 ? b0 + step : b0;
-                px1 = spec_axis == 1 ? b1 + step : b1;
-            }
+        const bool tree = SPEC && spec_axis >= 0 && !first;                   // wave-uniform
+        double Dpre_l = Delta, ps_l = 0.0;                                    // per slot: radius and signed step of its hypothesis
+        if (tree) {
+            const int k = spec_axis;
+            const double pk = k == 0 ? p[0] : p[1];
+            const bool pos = pk > 0;
+            const double D2 = 2.0 * Delta;
+            const double dq0 = 0.25 * sqrt64(p[0] * p[0] + p[1] * p[1]);      // radius after rejecting the trial (tr_update)
+            const double dq1 = 0.25 * sqrt64(D2 * D2);                        // ... after accepting it, doubling, and rejecting that
+            const double dq3 = 0.25 * sqrt64(dq0 * dq0);                      // ... after rejecting twice
+            const double xk = k == 0 ? x[0] : x[1], xek = k == 0 ? xe[0] : xe[1];
+            const double u = xk + (pos ? dq0 : -dq0);                         // slot 3's point
+            const int sl = slot_of_lane;
+            const bool root = sl == 0 || sl == 3 || sl == 8 || sl == 9;       // hypotheses that keep the current point x
+            Dpre_l = sl == 0 || sl == 9 ? Delta : sl <= 2 ? D2 : sl == 3 ? dq0 : sl <= 5 ? dq1 : sl <= 7 ? 2.0 * dq0 : dq3;
+            const bool pos_l = root ? pos : (sl == 1 || sl == 4 || sl == 6);
+            ps_l = (sl == 0 || sl == 9) ? pk : (pos_l ? Dpre_l : -Dpre_l);
+            const double from = root ? xk : (sl == 6 || sl == 7) ? u : xek;
+            const double at = from + ps_l;
+            if (sl >= 1 && sl <= 8) { px0 = k == 0 ? at : xe[0]; px1 = k == 1 ? at : xe[1]; }
         }
         double res, w[3];
         bool guard_l = false;
@@ -1184,9 +1233,111 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         STAMP(c_batch)
         int slot = 0;
         bool stop = false;
+        bool look = false;
+        if (tree) {
+            // ---- tree consume: the bookkeeping of every slot under its own hypothesis, all slots at once ------------
+            const int k = spec_axis;
+            const int sl = slot_of_lane;
+            double fnl[2], Jnl[2][2];
+            bool finl;
+            slot_collect(res, px0, px1, 6 * sl, fnl, Jnl, finl);
+            const double cnl = 0.5 * (fnl[0] * fnl[0] + fnl[1] * fnl[1]);
+            // the state a hypothesis starts from: the current one (slots 0, 3, 8), the trial accepted (1, 2, 4, 5: slot 0's
+            // evaluation) or the retry accepted (6, 7: slot 3's evaluation)
+            const int cls = (sl == 1 || sl == 2 || sl == 4 || sl == 5) ? 1 : (sl == 6 || sl == 7) ? 2 : 0;
+            double xp[2], fp[2], Jp[2][2], cp;
+            {
+                const double a0 = bcast(fnl[0], 0), a1 = bcast(fnl[1], 0), b0 = bcast(fnl[0], 18), b1 = bcast(fnl[1], 18);
+                fp[0] = cls == 0 ? f[0] : cls == 1 ? a0 : b0;
+                fp[1] = cls == 0 ? f[1] : cls == 1 ? a1 : b1;
+                for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) {
+                    const double ja = bcast(Jnl[r][c], 0), jb = bcast(Jnl[r][c], 18);
+                    Jp[r][c] = cls == 0 ? J[r][c] : cls == 1 ? ja : jb;
+                }
+                const double ca = bcast(cnl, 0), cb3 = bcast(cnl, 18);
+                cp = cls == 0 ? cost : cls == 1 ? ca : cb3;
+                const double u0 = bcast(px0, 18), u1 = bcast(px1, 18);
+                xp[0] = cls == 0 ? x[0] : cls == 1 ? xe[0] : u0;
+                xp[1] = cls == 0 ? x[1] : cls == 1 ? xe[1] : u1;
+            }
+            double gp[2], pl[2];
+            gp[0] = Jp[0][0] * fp[0] + Jp[1][0] * fp[1];
+            gp[1] = Jp[0][1] * fp[0] + Jp[1][1] * fp[1];
+            pl[0] = k == 0 ? ps_l : 0.0; pl[1] = k == 1 ? ps_l : 0.0;
+            const double predl = predicted_of(Jp, pl, gp);
+            double Dl = Dpre_l, dql;
+            int terml;
+            bool accl;
+            tr_update(finl, pl, xp, cp, cnl, predl, Dl, dql, terml, accl);
+            // the state after the step and what the solver does next (the tests of the serial loop below and of next_step)
+            double xs[2], fs[2], Js[2][2], gs[2];
+            xs[0] = accl ? px0 : xp[0]; xs[1] = accl ? px1 : xp[1];
+            fs[0] = accl ? fnl[0] : fp[0]; fs[1] = accl ? fnl[1] : fp[1];
+            const double cs = accl ? cnl : cp;
+            for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Js[r][c] = accl ? Jnl[r][c] : Jp[r][c];
+            gs[0] = Js[0][0] * fs[0] + Js[1][0] * fs[1];
+            gs[1] = Js[0][1] * fs[0] + Js[1][1] * fs[1];
+            const double g_norm = fmax(fabs(gs[0]), fabs(gs[1]));
+            const bool donel = terml != 0 || (accl && (g_norm < LSQ_GTOL || !(g_norm < INFINITY)));
+            const bool z0 = Js[0][0] == 0.0 && Js[1][0] == 0.0, z1 = Js[0][1] == 0.0 && Js[1][1] == 0.0;
+            const bool same_axis = (z0 != z1) && (z0 ? 1 : 0) == k;
+            const bool plus = !((k == 0 ? gs[0] : gs[1]) > 0);                 // next_step: pk = gk > 0 ? -Delta : Delta
+            // outcome: 1 / 2 accepted, radius doubled, next step + / -; 3 rejected, radius quartered, same direction again;
+            // 0 anything else (termination, a kept radius, another regime): the serial loop below takes it from there
+            int codel = 0;
+            if (!donel && same_axis) {
+                if (accl) codel = Dl == 2.0 * Dpre_l ? (plus ? 1 : 2) : 0;
+                else codel = (Dl == dql && plus == (ps_l > 0)) ? 3 : 0;
+            }
+            // ---- walk the tree along the outcomes that came true (wave-uniform) ----
+            int cur = 0, last = -1, last_acc = -1, consumed = 0;
+            for (;;) {
+                if (nfev + 1 >= max_nfev) break;                               // the budget test belongs to the serial loop
+                const int at = 6 * cur;
+                const int code = __builtin_amdgcn_readlane(codel, at);
+                if (code == 0) break;
+                if (it_w && sub == 0 && nfev < MISTI_TRACE_MAX_ITER) {
+                    double* r = it_w + ((int64_t)t * MISTI_TRACE_MAX_ITER + nfev) * 2;
+                    r[0] = bcast(px0, at); r[1] = bcast(px1, at);
+                }
+                ++nfev; ++consumed; last = cur;
+                if (__builtin_amdgcn_readlane((int)guard_l, at)) dg.guard = true;
+                if (__builtin_amdgcn_readlane((int)accl, at)) last_acc = cur;
+                int child = -1;
+                if (cur == 0) child = code;
+                else if (cur == 1) child = code == 3 ? 4 : -1;
+                else if (cur == 2) child = code == 3 ? 5 : -1;
+                else if (cur == 3) child = code == 1 ? 6 : code == 2 ? 7 : 8;
+                if (child < 0) break;
+                cur = child;
+            }
+            if (consumed > 0) {
+                const int at = 6 * last;
+                x[0] = bcast(xs[0], at); x[1] = bcast(xs[1], at);
+                f[0] = bcast(fs[0], at); f[1] = bcast(fs[1], at);
+                for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = bcast(Js[r][c], at);
+                cost = bcast(cs, at);
+                Delta = bcast(Dl, at);
+                if (last_acc >= 0) { vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2]; vk_base = 6 * last_acc; have_sv = false; }
+                g[0] = J[0][0] * f[0] + J[1][0] * f[1];
+                g[1] = J[0][1] * f[0] + J[1][1] * f[1];
+                predicted = next_step<GROUP>(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm, spec_axis);
+                xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
+                dg.spec += consumed - 1;
+                look = true;
+            }
+            STAMP(c_tree)
+        }
         // ---- consume: trust-region bookkeeping (trf_no_bounds) for the needed point, and again while the next point
         //      asked for is one of those evaluated in this pass ---------------------------------------------------
-        for (;;) {
+        for (;; look = true) {
+            if (look) {
+                // was the point now needed evaluated in this pass?  (lanes of role 0 carry their slot's point)
+                const unsigned long long hit = __ballot(role == 0 && lane < 6 * SPEC_SLOTS && px0 == xe[0] && px1 == xe[1]);
+                if (hit == 0) break;
+                slot = (__ffsll((long long)hit) - 1) / 6;
+                dg.spec += 1;
+            }
             double fn[2], Jn[2][2];
             bool finite;
             if (it_w && sub == 0) {
@@ -1210,22 +1361,11 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 alpha = 0.0;
                 accept = true;
             } else {
-                // straight-line (selects, no branches but the rare alpha rescale): the same expressions as SciPy's
                 ++nfev;
-                const double sn2 = p[0] * p[0] + p[1] * p[1];
-                const double dq = 0.25 * sqrt64(sn2);                            // radius after a poor or non-finite step
-                const double actual = cost - cost_new;
-                const double rq = actual * rcp64(predicted);
-                const double ratio = predicted > 0 ? rq : ((predicted == 0 && actual == 0) ? 1.0 : 0.0);
-                const double Delta_new = ratio < 0.25 ? dq                       // update_tr_radius, common.py:222-245
-                                         : ((ratio > 0.75 && sn2 > 0.9025 * Delta * Delta) ? 2.0 * Delta : Delta);
-                const bool f_ok = actual < LSQ_FTOL * cost && ratio > 0.25;      // check_termination, common.py:705-717
-                const double lim = LSQ_XTOL * (LSQ_XTOL + sqrt64(x[0] * x[0] + x[1] * x[1]));
-                const bool x_ok = sn2 < lim * lim;
-                term = !finite ? 0 : ((f_ok && x_ok) ? 4 : f_ok ? 2 : x_ok ? 3 : 0);
-                if (uni<GROUP>(finite && term == 0 && alpha != 0.0)) alpha *= Delta * rcp64(Delta_new);
-                Delta = !finite ? dq : (term == 0 ? Delta_new : Delta);
-                accept = finite && actual > 0;
+                const double Delta_old = Delta;
+                double dq;
+                tr_update(finite, p, x, cost, cost_new, predicted, Delta, dq, term, accept);
+                if (uni<GROUP>(finite && term == 0 && alpha != 0.0)) alpha *= Delta_old * rcp64(Delta);   // trf.py:515
             }
             // accepted: the trial becomes the current point (selects; g recomputed from whatever (J, f) is current)
             x[0] = accept ? xe[0] : x[0]; x[1] = accept ? xe[1] : x[1];
@@ -1256,11 +1396,6 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
             STAMP(c_next)
             if (!SPEC) break;
-            // was the point now needed evaluated in this pass?  (lanes of role 0 carry their slot's point)
-            const unsigned long long hit = __ballot(role == 0 && lane < 6 * SPEC_SLOTS && px0 == xe[0] && px1 == xe[1]);
-            if (hit == 0) break;
-            slot = (__ffsll((long long)hit) - 1) / 6;
-            dg.spec += 1;
         }
         if (uni<GROUP>(stop)) break;
         STAMP(c_book)
@@ -1273,7 +1408,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             double* r = cb.work + slot * 6;
             r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.spec; r[4] = dg.max_nfev; r[5] = dg.lm;
 #ifdef MISTI_STAMP
-            r[0] = (double)c_collect; r[1] = (double)c_update; r[2] = (double)c_next;
+            r[0] = (double)c_tree; r[1] = (double)(c_collect + c_update); r[2] = (double)c_next;
             r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
 #endif
         } else {
