@@ -1205,10 +1205,10 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         // bookkeeping of all of them is then done at once, one hypothesis per slot (tree consume below): up to three
         // solver steps per pass, bit for bit the same iteration.  A guess never consumed costs nothing.
         double px0 = xe[0], px1 = xe[1];
-        const bool tree = SPEC && spec_axis >= 0 && !first;                   // wave-uniform
+        const bool tree = SPEC && uni<GROUP>(spec_axis >= 0 && !first);       // wave-uniform
         double Dpre_l = Delta, ps_l = 0.0;                                    // per slot: radius and signed step of its hypothesis
         if (tree) {
-            const int k = spec_axis;
+            const int k = __builtin_amdgcn_readfirstlane(spec_axis);
             const double pk = k == 0 ? p[0] : p[1];
             const bool pos = pk > 0;
             const double D2 = 2.0 * Delta;
@@ -1236,29 +1236,23 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         bool look = false;
         if (tree) {
             // ---- tree consume: the bookkeeping of every slot under its own hypothesis, all slots at once ------------
-            const int k = spec_axis;
+            const int k = __builtin_amdgcn_readfirstlane(spec_axis);
             const int sl = slot_of_lane;
             double fnl[2], Jnl[2][2];
             bool finl;
             slot_collect(res, px0, px1, 6 * sl, fnl, Jnl, finl);
             const double cnl = 0.5 * (fnl[0] * fnl[0] + fnl[1] * fnl[1]);
             // the state a hypothesis starts from: the current one (slots 0, 3, 8), the trial accepted (1, 2, 4, 5: slot 0's
-            // evaluation) or the retry accepted (6, 7: slot 3's evaluation)
-            const int cls = (sl == 1 || sl == 2 || sl == 4 || sl == 5) ? 1 : (sl == 6 || sl == 7) ? 2 : 0;
+            // evaluation) or the retry accepted (6, 7: slot 3's evaluation).  One gather per quantity: lane 60 (idle, it
+            // repeats slot 0) is lent the current state, so every slot pulls from lane 60, 0 or 18.
             double xp[2], fp[2], Jp[2][2], cp;
             {
-                const double a0 = bcast(fnl[0], 0), a1 = bcast(fnl[1], 0), b0 = bcast(fnl[0], 18), b1 = bcast(fnl[1], 18);
-                fp[0] = cls == 0 ? f[0] : cls == 1 ? a0 : b0;
-                fp[1] = cls == 0 ? f[1] : cls == 1 ? a1 : b1;
-                for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) {
-                    const double ja = bcast(Jnl[r][c], 0), jb = bcast(Jnl[r][c], 18);
-                    Jp[r][c] = cls == 0 ? J[r][c] : cls == 1 ? ja : jb;
-                }
-                const double ca = bcast(cnl, 0), cb3 = bcast(cnl, 18);
-                cp = cls == 0 ? cost : cls == 1 ? ca : cb3;
-                const double u0 = bcast(px0, 18), u1 = bcast(px1, 18);
-                xp[0] = cls == 0 ? x[0] : cls == 1 ? xe[0] : u0;
-                xp[1] = cls == 0 ? x[1] : cls == 1 ? xe[1] : u1;
+                const bool lend = lane == 60;
+                const int src = (sl == 1 || sl == 2 || sl == 4 || sl == 5) ? 0 : (sl == 6 || sl == 7) ? 18 : 60;
+                fp[0] = __shfl(lend ? f[0] : fnl[0], src, 64); fp[1] = __shfl(lend ? f[1] : fnl[1], src, 64);
+                for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Jp[r][c] = __shfl(lend ? J[r][c] : Jnl[r][c], src, 64);
+                cp = __shfl(lend ? cost : cnl, src, 64);
+                xp[0] = __shfl(lend ? x[0] : px0, src, 64); xp[1] = __shfl(lend ? x[1] : px1, src, 64);
             }
             double gp[2], pl[2];
             gp[0] = Jp[0][0] * fp[0] + Jp[1][0] * fp[1];
@@ -1321,7 +1315,12 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 if (last_acc >= 0) { vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2]; vk_base = 6 * last_acc; have_sv = false; }
                 g[0] = J[0][0] * f[0] + J[1][0] * f[1];
                 g[1] = J[0][1] * f[0] + J[1][1] * f[1];
-                predicted = next_step<GROUP>(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm, spec_axis);
+                // the step after a consumed slot is again the rank-one one along k (that is what its outcome code says):
+                // next_step's rank-one branch, without the rest of it
+                const double pk = (k == 0 ? g[0] : g[1]) > 0 ? -Delta : Delta;
+                p[0] = k == 0 ? pk : 0.0; p[1] = k == 1 ? pk : 0.0;
+                alpha = 0.0;
+                predicted = predicted_of(J, p, g);
                 xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
                 dg.spec += consumed - 1;
                 look = true;
