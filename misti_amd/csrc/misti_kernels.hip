@@ -240,12 +240,18 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         dg.dense += 1; dg.squarings += sq;
         double scl = ldexp(1.0, -sq);
         double B[3][3] = {{-d0 * scl, 0.0, mu1 * scl}, {0.0, -d1 * scl, mu0 * scl}, {2.0 * mu0 * scl, 2.0 * mu1 * scl, -d2 * scl}};
-        double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-        for (int k = 12; k >= 1; --k) {                      // E = I + B E / k
+        // Horner, E = I + B E / k for k = 12 .. 1.  The first step (E = I) is B / 12 + I; B[0][1] = B[1][0] = 0 are left out
+        // of the products - with the fused forms spelt out both give the bits of the full 3x3 product for finite entries.
+        double E[3][3];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { const double b12 = B[r][c] * c_inv[12]; E[r][c] = b12 + (r == c ? 1.0 : 0.0); }   // two roundings, as in the loop
+        for (int k = 11; k >= 1; --k) {
             double inv = c_inv[k];
             double Tm[3][3];
-            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c)
-                Tm[r][c] = ((B[r][0] * E[0][c] + B[r][1] * E[1][c]) + B[r][2] * E[2][c]) * inv;
+            for (int c = 0; c < 3; ++c) {
+                Tm[0][c] = fma(B[0][2], E[2][c], B[0][0] * E[0][c]) * inv;
+                Tm[1][c] = fma(B[1][2], E[2][c], B[1][1] * E[1][c]) * inv;
+                Tm[2][c] = ((B[2][0] * E[0][c] + B[2][1] * E[1][c]) + B[2][2] * E[2][c]) * inv;
+            }
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) E[r][c] = Tm[r][c] + (r == c ? 1.0 : 0.0);
         }
         for (int i = 0; i < sq; ++i) {
