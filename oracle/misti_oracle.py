@@ -40,6 +40,10 @@ from math import exp, log, sqrt
 import numpy as np
 from scipy import linalg, optimize, special
 
+# Test hook (tools/self_perturbation.py --internal): a function applied to every pair-chain matrix exponential, to
+# measure how far ONE ULP there moves the result - the reference's internal indeterminacy (tests/parity.py).
+EXPM_HOOK = None
+
 __all__ = ["OracleError", "OracleModel", "TWO_POP", "ONE_POP", "STATUS"]
 
 STATUS = {"ok": 0, "negative_param": 1, "correction_failed": 2}
@@ -274,7 +278,8 @@ class _PairChain:
 
     def _expm(self, M):                                     # CorrectLambda.py:58-62
         self.count_fun_evals += 1
-        return linalg.expm(np.dot(M, self.T))
+        e = linalg.expm(np.dot(M, self.T))
+        return e if EXPM_HOOK is None else EXPM_HOOK(e)
 
     # -- one-population helpers ------------------------------------------
     def ect_one_pop(self, lam):                             # CorrectLambda.py:67-72

@@ -14,8 +14,10 @@ KIND_OF_SITE = {"two_pop_cp": 3, "two_pop_ect": 3, "no_migration": 2, "single_po
 
 
 def load_traces():
-    d = json.load(gzip.open(os.path.join(GOLDEN, "golden_traces.json.gz"), "rt"))
-    return {c["name"]: c for c in d["cases"]}
+    out = {}
+    for f in ("golden_traces.json.gz", "golden_campaign_traces.json.gz"):
+        out.update({c["name"]: c for c in json.load(gzip.open(os.path.join(GOLDEN, f), "rt"))["cases"]})
+    return out
 
 
 def hip_trace(case):

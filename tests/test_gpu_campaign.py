@@ -25,17 +25,18 @@ def test_random_batches_against_the_oracle():
     assert s["candidates"] == n_jobs == 7648
     # failure against value only where the reference itself flips under a 2^-48 perturbation
     assert s["status_mismatch"] <= 3, rep["bad"][:5]
-    comparable = s["tight"] + s["self_bound"] + s["outside"]
+    comparable = s["tight"] + s["self_bound"] + s["internal_bound"] + s["outside"]
     assert comparable >= 7000
     # the contract per candidate (tests/parity.py): 1e-9 (+ rounding floor), or 10 x the reference's own spread under 4-64
-    # perturbations of 2^-48 for THAT candidate (tests/golden/campaign_seed1.json.gz, tools/self_perturbation.py)
+    # perturbations of 2^-48 for THAT candidate, or (the 162 candidates beyond twice that spread were studied) under one
+    # ulp in its own pair-chain expm (tests/golden/campaign_seed1.json.gz, tools/self_perturbation.py)
     assert s["tight"] >= 5000
     # Discrete stop/continue flips of SciPy's tests are rare events of the reference too (a few per thousand
     # ill-conditioned solves): a candidate whose flip the 4-64 perturbed reference runs did not happen to sample lands
     # outside.  The fixture was studied against one build; another rounding realisation moves which candidates those are,
     # so a small number is tolerated here - all of them in the noise-driven class - and profiles/ reports the exact count.
     assert s["outside"] <= comparable // 150, rep["outside"][:10]
-    for rel, spread, idx, ci, k, split, run, cpfit, kinds in rep["outside"]:
+    for rel, spread, idx, ci, k, split, run, cpfit, kinds, internal in rep["outside"]:
         c = cases[ci]
         default_mig = (not c["flags"]["cpfit"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
         assert run >= 5.0 or default_mig or rel <= 1e-8, (idx, rel, spread, run)

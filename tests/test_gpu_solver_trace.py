@@ -17,7 +17,7 @@ from solver_trace_util import compare_case, load_traces
 pytestmark = pytest.mark.gpu
 
 TRACES = load_traces()
-CASES = {c["name"]: c for f in ("golden_small", "golden_synthetic", "golden_sweep") for c in load_golden(f)}
+CASES = {c["name"]: c for f in ("golden_small", "golden_synthetic", "golden_sweep", "golden_campaign") for c in load_golden(f)}
 
 
 @pytest.mark.parametrize("name", sorted(TRACES), ids=sorted(TRACES))

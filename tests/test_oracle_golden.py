@@ -12,6 +12,7 @@ from oracle.misti_oracle import OracleModel, TWO_POP, ONE_POP
 SMALL = load_golden("golden_small")
 SYNTH = load_golden("golden_synthetic")
 SWEEP = load_golden("golden_sweep")
+CAMPAIGN = load_golden("golden_campaign")
 # the oracle restates the reference operation by operation on the same SciPy, so
 # agreement is at rounding level; 1e-12 leaves room for a different BLAS build
 RTOL = 1e-12
@@ -56,6 +57,13 @@ def test_synthetic(case):
 @pytest.mark.parametrize("case", SWEEP, ids=[c["name"] for c in SWEEP])
 def test_sweep(case):
     """The README's four-band st x mc sweep (README.md:110-115), one reference run per grid point."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", CAMPAIGN, ids=[c["name"] for c in CAMPAIGN])
+def test_campaign_worst(case):
+    """The random campaign's worst candidates (tools/random_campaign.py), run through the reference: the oracle the
+    campaign is judged against reproduces the reference on them."""
     check(case)
 
 

@@ -3,10 +3,11 @@
 
     python tools/parity_report.py > profiles/rNN_parity_goldens.txt
 
-Per case: relative llk error, the two clauses of the contract (tests/parity.py) - the 1e-9 tolerance (+ rounding floor)
+Per case: relative llk error, the clauses of the contract (tests/parity.py) - the 1e-9 tolerance (+ rounding floor)
 and 10 x the reference's own measured indeterminacy (`spread`: largest relative change of the reference's llh under
-2^-48 input perturbations, 3 kinds for determined cases, 9 for the others) - which clause the case falls under and
-the FACTOR err / spread for the second; max relative JAFS and lc errors."""
+2^-48 input perturbations, 3 kinds for determined cases, 9 for the others, 32 for the campaign's; `internal`: the same
+under one ulp in its own pair-chain matrix exponential, 16 runs) - which clause the case falls under and the FACTOR
+err / spread (or err / internal) for it; max relative JAFS and lc errors."""
 import contextlib
 import io
 import os
@@ -19,15 +20,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import load_golden                                   # noqa: E402
-from parity import SELF_FACTOR, engine_args, llk_tol, spread_of    # noqa: E402
+from parity import SELF_FACTOR, engine_args, internal_of, llk_tol, spread_of    # noqa: E402
 from misti_amd.engine import MigrationInference                    # noqa: E402
 
 
 def main():
     rows = []
-    n_tight = n_self = n_out = n_fail_ok = n_fail_bad = 0
-    worst_factor = 0.0
-    for f in ("golden_small", "golden_synthetic", "golden_sweep"):
+    n_tight = n_self = n_int = n_out = n_fail_ok = n_fail_bad = 0
+    worst_factor = worst_int = 0.0
+    for f in ("golden_small", "golden_synthetic", "golden_sweep", "golden_campaign"):
         for c in load_golden(f):
             o = c["out"]
             args, kw = engine_args(c["in"])
@@ -36,16 +37,17 @@ def main():
                 llh = m.JAFSLikelihood(list(c["in"]["params"]))
             if o["llh"] is None or llh == -np.inf:
                 both = o["llh"] is None and llh == -np.inf
-                flips = (o.get("pert_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0)
+                flips = (o.get("pert_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0 or o.get("internal_fail", 0) > 0)
                 ok = both or flips
                 n_fail_ok += ok
                 n_fail_bad += not ok
                 rows.append((c["name"], "ref -inf" if o["llh"] is None else "%.6g" % o["llh"], "hip -inf" if llh == -np.inf else "%.6g" % llh,
-                             "", "", "", "", "", "both fail" if both else ("reference flips" if flips else "MISMATCH")))
+                             "", "", "", "", "", "", "both fail" if both else ("reference flips" if flips else "MISMATCH")))
                 continue
             err = abs(llh - o["llh"]) / abs(o["llh"])
             tol = llk_tol(o["llh"], c["in"]["sfs"], o["JAFS"], bool(kw.get("unfolded"))) / abs(o["llh"])
             spread = spread_of(o)
+            internal = internal_of(o)
             ej = np.max(np.abs(np.array(m.JAFS) / np.array(o["JAFS"]) - 1))
             el = np.max(np.abs(np.array(m.lc) / np.array(o["lc"]) - 1))
             if err <= tol:
@@ -55,18 +57,23 @@ def main():
                 cls, factor = "self", "%.2f" % (err / spread)
                 worst_factor = max(worst_factor, err / spread)
                 n_self += 1
+            elif internal is not None and err <= SELF_FACTOR * internal:
+                cls, factor = "internal", "%.2f" % (err / internal)
+                worst_int = max(worst_int, err / internal)
+                n_int += 1
             else:
-                cls, factor = "OUTSIDE", "%.2f" % (err / spread) if spread else "inf"
+                cls, factor = "OUTSIDE", "%.2f" % (err / max(spread or 0.0, internal or 0.0)) if (spread or internal) else "inf"
                 n_out += 1
-            rows.append((c["name"], "%.2e" % err, "%.2e" % tol, "%.2e" % spread if spread is not None else "-", factor,
+            rows.append((c["name"], "%.2e" % err, "%.2e" % tol, "%.2e" % spread if spread is not None else "-", "%.2e" % internal if internal is not None else "-", factor,
                          "%.1e" % ej, "%.1e" % el, "%d/%d" % (o.get("pert_fail", 0), len(o.get("pert_llh", []))), cls))
     w = max(len(r[0]) for r in rows)
-    print("%-*s %10s %10s %10s %7s %9s %9s %6s %s" % (w, "case", "llk rel", "tol 1e-9", "ref spread", "factor", "JAFS rel", "lc rel", "pfail", "clause"))
+    print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %s" % (w, "case", "llk rel", "tol 1e-9", "ref spread", "internal", "factor", "JAFS rel", "lc rel", "pfail", "clause"))
     for r in rows:
-        print("%-*s %10s %10s %10s %7s %9s %9s %6s %s" % ((w,) + r))
+        print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %s" % ((w,) + r))
     print()
-    print("finite on both sides: %d within 1e-9 (+ floor), %d within %g x the reference's own spread (worst factor %.2f), %d OUTSIDE the contract"
-          % (n_tight, n_self, SELF_FACTOR, worst_factor, n_out))
+    print("finite on both sides: %d within 1e-9 (+ floor), %d within %g x the reference's own spread under input perturbations (worst factor %.2f),"
+          % (n_tight, n_self, SELF_FACTOR, worst_factor))
+    print("    %d more within %g x its spread under one ulp in its own expm (worst factor %.2f), %d OUTSIDE the contract" % (n_int, SELF_FACTOR, worst_int, n_out))
     print("failures: %d agree or are reference flips, %d mismatches" % (n_fail_ok, n_fail_bad))
 
 

@@ -105,8 +105,8 @@ def main():
 
 def load_ref(path, models, seed, n_jobs):
     """Oracle results: the full file of --make-ref or the compact committed fixture.  Rows become
-    (llk, jafs or None, status, rate x length, spread, perturbed runs without a value, kinds): the last three are
-    None where tools/self_perturbation.py has not studied the candidate."""
+    (llk, jafs or None, status, rate x length, spread, perturbed runs without a value, kinds, internal spread, internal
+    runs without a value, internal runs): None where tools/self_perturbation.py has not studied the candidate."""
     import gzip
     import json
     d = json.load(gzip.open(path, "rt") if path.endswith(".gz") else open(path))
@@ -114,9 +114,10 @@ def load_ref(path, models, seed, n_jobs):
     out = []
     for r in d["ref"]:
         if len(r) == 4 and (r[1] is None or isinstance(r[1], list)):      # --make-ref: llk, jafs, status, run
-            out.append((r[0], r[1], r[2], r[3], None, None, None))
+            out.append((r[0], r[1], r[2], r[3], None, None, None, None, None, None))
         else:                                                               # fixture: llk, status, run [, spread, nfail, kinds]
             ext = tuple(r[3:6]) if len(r) >= 6 else (None, None, None)
+            ext += tuple(r[6:9]) if len(r) >= 9 else (None, None, None)      # internal spread, its failed runs, its runs
             out.append((r[0], None, r[1], r[2]) + ext)
     return out
 
@@ -124,25 +125,26 @@ def load_ref(path, models, seed, n_jobs):
 def compare(cases, ref, dump=""):
     """Evaluate every model as one batch through the C ABI and compare candidate by candidate under the contract of
     tests/parity.py: |llk - ref| <= 1e-9 |ref| + rounding floor, or <= 10 x the reference's own measured spread for
-    that candidate; a failure against a value (either way) only where the reference itself flips under perturbation."""
+    that candidate (under 2^-48 input perturbations, or under one ulp in its own pair-chain expm); a failure against a
+    value (either way) only where the reference itself flips under perturbation."""
     from parity import SELF_FACTOR, llk_tol
     from misti_amd.engine import Engine
-    stats = dict(candidates=0, both_fail=0, status_mismatch=0, status_flip_ok=0, tight=0, self_bound=0, outside=0, unstudied=0)
-    worst_tight = worst_factor = 0.0
-    bad, outside, factors, dumped = [], [], [], []
+    stats = dict(candidates=0, both_fail=0, status_mismatch=0, status_flip_ok=0, tight=0, self_bound=0, internal_bound=0, outside=0, unstudied=0)
+    worst_tight = worst_factor = worst_internal = 0.0
+    bad, outside, factors, ifactors, dumped = [], [], [], [], []
     pos = 0
     for ci, c in enumerate(cases):
         n = len(c["split"])
         with Engine(c["times"], c["lh"], c["bands"], c["pulses"], n_param=c["P"], sample_date=c["sd"], **c["flags"]) as e:
             r = e.evaluate(c["split"], c["params"], [c["sfs"]])
         for k in range(n):
-            o_llk, o_jafs, o_st, run, spread, nfail, kinds = ref[pos + k]
+            o_llk, o_jafs, o_st, run, spread, nfail, kinds, internal, ifail, iruns = ref[pos + k]
             stats["candidates"] += 1
             dumped.append([float(r.llk[k, 0]) if np.isfinite(r.llk[k, 0]) else None, int(r.status[k])])
             if o_st != 0 or r.status[k] != 0:
                 if o_st != 0 and r.status[k] != 0:
                     stats["both_fail"] += 1
-                elif kinds and ((o_st != 0 and nfail < kinds) or (o_st == 0 and nfail > 0)):
+                elif (kinds and ((o_st != 0 and nfail < kinds) or (o_st == 0 and nfail > 0))) or (o_st == 0 and ifail):
                     stats["status_flip_ok"] += 1          # the reference itself flips between a value and a failure
                 else:
                     stats["status_mismatch"] += 1
@@ -157,29 +159,38 @@ def compare(cases, ref, dump=""):
                 stats["self_bound"] += 1
                 worst_factor = max(worst_factor, rel / spread)
                 factors.append((rel / spread, rel, spread, pos + k, ci, k))
+            elif internal is not None and internal > 0 and rel <= SELF_FACTOR * internal:
+                stats["internal_bound"] += 1
+                worst_internal = max(worst_internal, rel / internal)
+                ifactors.append((rel / internal, rel, internal, spread, pos + k, ci, k))
             else:
                 stats["outside"] += 1
                 stats["unstudied"] += spread is None
-                outside.append((rel, spread, pos + k, ci, k, float(c["split"][k]), run, c["flags"]["cpfit"], kinds))
+                outside.append((rel, spread, pos + k, ci, k, float(c["split"][k]), run, c["flags"]["cpfit"], kinds, internal))
         pos += n
     if dump:
         import json
         json.dump({"n": len(dumped), "hip": dumped}, open(dump, "w"))
     outside.sort(key=lambda b: -b[0])
     factors.sort(reverse=True)
-    return dict(stats=stats, worst_tight=worst_tight, worst_factor=worst_factor, bad=bad, outside=outside, factors=factors)
+    ifactors.sort(reverse=True)
+    return dict(stats=stats, worst_tight=worst_tight, worst_factor=worst_factor, worst_internal=worst_internal, bad=bad, outside=outside,
+                factors=factors, ifactors=ifactors)
 
 
 def print_report(rep):
     stats = rep["stats"]
     print(stats)
     print("within 1e-9 (+ rounding floor): %d, worst %.3g" % (stats["tight"], rep["worst_tight"]))
-    print("within 10 x the reference's own measured spread: %d, worst factor %.2f" % (stats["self_bound"], rep["worst_factor"]))
+    print("within 10 x the reference's own measured spread under input perturbations: %d, worst factor %.2f" % (stats["self_bound"], rep["worst_factor"]))
     for f in rep["factors"][:8]:
         print("   factor %.2f  rel %.3g  spread %.3g  candidate %d (model %d cand %d)" % f)
+    print("within 10 x its spread under one ulp in its own pair-chain expm: %d more, worst factor %.2f" % (stats["internal_bound"], rep["worst_internal"]))
+    for f in rep["ifactors"][:12]:
+        print("   factor %.2f  rel %.3g  internal %.3g  (input spread %s)  candidate %d (model %d cand %d)" % f)
     print("OUTSIDE the contract: %d (%d of them not studied by tools/self_perturbation.py)" % (stats["outside"], stats["unstudied"]))
     for b in rep["outside"][:20]:
-        print("   rel %.3g  spread %s  candidate %d (model %d cand %d) split %.3f  rate x len %.3g  cpfit %s  kinds %s" % b)
+        print("   rel %.3g  spread %s  candidate %d (model %d cand %d) split %.3f  rate x len %.3g  cpfit %s  kinds %s  internal %s" % b)
     print("status: %d both fail, %d reference flips under perturbation, %d MISMATCHES" % (stats["both_fail"], stats["status_flip_ok"], stats["status_mismatch"]))
     for b in rep["bad"][:20]:
         print("  ", b)

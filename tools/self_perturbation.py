@@ -12,9 +12,14 @@ The parity contract (tests/parity.py) then allows the HIP path 10 x that spread 
     python tools/self_perturbation.py --fixture ... --kinds 16 --only scratch/violators.json      # denser sampling for some
     python tools/self_perturbation.py --fixture ... --reference --only ...                        # the reference itself (here only)
 
+    python tools/self_perturbation.py --fixture ... --internal 16 --only ...                      # one ulp in its own expm instead
+
 Results are appended to <fixture>.spread.jsonl (resumable) and merged into the fixture with --merge:
 every `ref` row becomes [llk, status, rate_x_len, spread, perturbed_runs_failed, kinds] for the candidates
-that were studied.
+that were studied, and [..., internal, internal_runs_failed, internal_runs] for those studied with --internal: the
+largest relative change of the oracle's llh when its pair-chain matrix exponential (the reference's
+scipy.linalg.expm at CorrectLambda.py:62) returns every entry moved by -1, 0 or +1 ulp at random
+(the second measurement of tests/parity.py; tests/golden/internal_noise.py does the same to the reference itself).
 """
 import argparse
 import gzip
@@ -78,6 +83,29 @@ def job(args):
     return {"i": idx, "kinds": kinds, "base": base, "vals": out, "reference": USE_REFERENCE}
 
 
+def internal_job(args):
+    """`runs` evaluations of one candidate with one-ulp noise in the oracle's pair-chain expm."""
+    import oracle.misti_oracle as om
+    idx, c, k, runs, base = args
+    out = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s in range(runs):
+            rng = np.random.default_rng(7000 + s)
+
+            def hook(e, rng=rng):
+                kk = rng.integers(-1, 2, e.shape)
+                return np.where(kk > 0, np.nextafter(e, np.inf), np.where(kk < 0, np.nextafter(e, -np.inf), e))
+            om.EXPM_HOOK = hook
+            try:
+                out.append(eval_one(c, k, c["times"], c["lh"]))
+            except BaseException:
+                out.append(None)
+            finally:
+                om.EXPM_HOOK = None
+    return {"i": idx, "internal_runs": runs, "base": base, "vals": out}
+
+
 def noisy_class(c, ref_row):
     default_mig = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
     return ref_row[2] >= 5.0 or default_mig
@@ -111,6 +139,7 @@ def main():
     ap.add_argument("--procs", type=int, default=7)
     ap.add_argument("--only", default="", help="JSON list of candidate indices to study (default: the whole noise-driven class)")
     ap.add_argument("--reference", action="store_true", help="run /root/reference itself instead of the oracle (build container only)")
+    ap.add_argument("--internal", type=int, default=0, help="instead: this many runs with one-ulp noise in the oracle's pair-chain expm (needs --only)")
     ap.add_argument("--merge", action="store_true", help="fold <fixture>.spread.jsonl into the fixture and exit")
     a = ap.parse_args()
     USE_REFERENCE = a.reference
@@ -124,6 +153,13 @@ def main():
     assert len(index) == d["n"]
     side = a.fixture + ".spread.jsonl"
     have, refruns = load_results(side)
+    side_int = a.fixture + ".internal.spread.jsonl"
+    have_int = {}
+    if os.path.exists(side_int):
+        for line in open(side_int):
+            r = json.loads(line)
+            if r["i"] not in have_int or have_int[r["i"]]["internal_runs"] < r["internal_runs"]:
+                have_int[r["i"]] = r
     if a.merge:
         n = 0
         for i, row in enumerate(d["ref"]):
@@ -132,8 +168,13 @@ def main():
                 spread, nfail, kinds = summarise(have[i], row[0] if row[1] == 0 else None)
                 row += [spread, nfail, kinds]
                 n += 1
+                if i in have_int and row[1] == 0:
+                    r = have_int[i]
+                    fin = [v for v in r["vals"] if v is not None]
+                    row += [max(abs(v - row[0]) / abs(row[0]) for v in fin) if fin else None, len(r["vals"]) - len(fin), r["internal_runs"]]
             d["ref"][i] = row
-        d["spread"] = ("rows of studied candidates: [llk, status, rate x length, spread, perturbed runs without a value, kinds]; "
+        d["spread"] = ("rows of studied candidates: [llk, status, rate x length, spread, perturbed runs without a value, kinds"
+                       " (, internal spread, internal runs without a value, internal runs)]; "
                        "tools/self_perturbation.py, perturbations of tests/parity.py")
         with gzip.open(a.fixture, "wt") as f:
             json.dump(d, f)
@@ -143,6 +184,20 @@ def main():
         todo = [int(i) for i in json.load(open(a.only))]
     else:
         todo = [i for i, (ci, k) in enumerate(index) if noisy_class(cases[ci], d["ref"][i])]
+    if a.internal:
+        assert a.only and not a.reference
+        todo = [i for i in todo if d["ref"][i][1] == 0 and (i not in have_int or have_int[i]["internal_runs"] < a.internal)]
+        print("%d candidates to study with %d noisy-expm runs each (oracle)" % (len(todo), a.internal), file=sys.stderr)
+        jobs = [(i, cases[index[i][0]], index[i][1], a.internal, d["ref"][i][0]) for i in todo]
+        with threadpool_limits(1), open(side_int, "a") as out:
+            with mp.get_context("fork").Pool(a.procs) as pool:
+                for n, r in enumerate(pool.imap_unordered(internal_job, jobs, chunksize=2)):
+                    out.write(json.dumps(r) + "\n")
+                    out.flush()
+                    if n % 100 == 0:
+                        print("studied %d / %d" % (n, len(jobs)), file=sys.stderr, flush=True)
+        print("done: %s" % side_int)
+        return
     tgt = refruns if a.reference else have
     todo = [i for i in todo if i not in tgt or tgt[i]["kinds"] < a.kinds]
     print("%d candidates to study with %d perturbations each (%s)" % (len(todo), a.kinds, "reference" if a.reference else "oracle"), file=sys.stderr)

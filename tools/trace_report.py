@@ -20,7 +20,7 @@ from conftest import load_golden                                 # noqa: E402
 
 def main():
     traces = load_traces()
-    cases = {c["name"]: c for f in ("golden_small", "golden_synthetic", "golden_sweep") for c in load_golden(f)}
+    cases = {c["name"]: c for f in ("golden_small", "golden_synthetic", "golden_sweep", "golden_campaign") for c in load_golden(f)}
     print("%-32s %6s %6s %-22s %-26s %5s %9s %9s" % ("case", "solves", "equal", "first differing solve", "ref (nfev,status) | hip", "iter", "rel there", "rel before"))
     for name, tr in traces.items():
         r = compare_case(cases[name], tr)
