@@ -310,6 +310,10 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // per wave and the trunk following it)
     auto shape = [&](int64_t est, int& cpw, bool& follow) {
         cpw = (est >= 0 && est <= 256) ? 1 : misti::correct_cands_per_wave(n_cand);
+        if (const char* e = getenv("MISTI_CHAINS_PER_WAVE")) {     // diagnostic override (scratch experiments), read per call
+            const int f = atoi(e);
+            if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10) cpw = f;
+        }
         follow = misti::trunk_follows(cpw, (int64_t)ntr);
     };
     // a batch is four launches (+1 for the default fit, +1 with more than LLK_INLINE_MAX replicates): setup | chains |

@@ -1748,8 +1748,16 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
 // Kernel 1 with the trunk following: 128-thread workgroups, wave 0 = the chain (one chain per wave),
 // wave 1 = its trunk.  LDS (doubles): kernel-1 staging [3 numT] | trunk xbuf [128] + rates [2 (numT+1)] |
 // hand-over rates [2 numT] | count, done flag [2] | per-interval constants of the chain (mu, pulse, exp(-lh T)) [6 numT].
+// Two waves per SIMD for the --cpfit instantiation: the chain wave is bound by the latency of its own dependent
+// instruction stream (one instruction per ~4.7 cycles), so a second wave on the SIMD costs it nothing (single batch
+// 1.884 -> 1.888 ms) and with 20 batches in flight the chip holds twice as many chains (2.38e7 -> 2.62e7 evals/s).
+// The register allocator gives up the 12 AGPRs for 28 bytes of scratch.  The default fit (256 VGPRs + 108 AGPRs) stays
+// at one wave.
+#ifndef MISTI_FOLLOW_WAVES
+#define MISTI_FOLLOW_WAVES 2
+#endif
 template <bool CPFIT>
-__global__ __launch_bounds__(128)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CPFIT ? MISTI_FOLLOW_WAVES : 1, CPFIT ? MISTI_FOLLOW_WAVES : 1)))
 void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
     extern __shared__ double lds[];
     double* tk = lds + 3 * (size_t)m.numT;
