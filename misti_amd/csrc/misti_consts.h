@@ -5,7 +5,10 @@ constexpr int NS2 = 44;               // two-population states
 constexpr int NS1 = 8;                // one-population states
 constexpr int MAXNZ = 4;              // off-diagonal entries per generator row
 constexpr int MAXPULSE = 12;          // entries per row of the pulse operator
-constexpr int WAVES_PER_BLOCK = 4;    // candidates per 256-thread workgroup
+#ifndef MISTI_WAVES_PER_BLOCK
+#define MISTI_WAVES_PER_BLOCK 4
+#endif
+constexpr int WAVES_PER_BLOCK = MISTI_WAVES_PER_BLOCK;    // candidates per workgroup of kernel 2 (one wavefront each)
 constexpr int TALBOT_N = 28;           // nodes of the Talbot contour (conjugate pairs folded: TALBOT_HALF solves)
 constexpr int TALBOT_HALF = TALBOT_N / 2;
 constexpr int INV_TABLE = 1024;         // reciprocal table for the series (also the cap on terms per series)

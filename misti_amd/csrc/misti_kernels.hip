@@ -213,6 +213,32 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
     if (INT) { vint[0] = b0; vint[1] = b1; vint[2] = b2; }
 }
 
+// Structural reduction of the pair chain.  With migration in one direction only (mu1 == 0: nothing enters "both in
+// population 0") and that state empty in both genomes - it is, exactly, from the first interval in which its rate ran
+// away: exp(-rate x length) underflows or falls below PAIR_EMPTY of the total - the three-state chain is the two-state one on (both in population 1, one in each), whose
+// generator [[-d1, mu0], [0, -d2]] is triangular:
+//     w1 = e^{-d1} v1 + mu0 phi v2,   w2 = e^{-d2} v2,   phi = (e^{-d1} - e^{-d2}) / (d2 - d1),   w0 = 0,
+// three exponentials instead of a 30-45 term series or a dense scaling-and-squaring on a matrix made stiff by a rate
+// (l0) that no longer enters the result.  This is exactly the solver's rank-one regime (correct_body): the Jacobian
+// column of l0 is zero because l0 is not read.  Mirror case (which = 2): mu0 == 0 and "both in population 1" empty.
+constexpr double PAIR_EMPTY = 1e-30;
+__device__ __forceinline__ void pair_reduced(int which, double l0, double l1, double mu0, double mu1, double v[3], bool ok) {
+    if (!ok) { l0 = 0.0; l1 = 0.0; }
+    const double dk = which == 1 ? 2.0 * mu1 + l1 : 2.0 * mu0 + l0;      // exit rate of the state that is left
+    const double d2 = mu0 + mu1;
+    const double mu = which == 1 ? mu0 : mu1;                             // "one in each" -> that state
+    const double vk = which == 1 ? v[1] : v[0];
+    const double a = -dk, c = -d2;
+    const double ax = fabs(a - c);
+    const double phi = exp(fmax(a, c)) * (ax == 0.0 ? 1.0 : -expm1(-ax) / ax);
+    const double wk = exp(a) * vk + mu * phi * v[2];
+    const double w2 = exp(c) * v[2];
+    v[0] = which == 1 ? 0.0 : wk;
+    v[1] = which == 1 ? wk : 0.0;
+    v[2] = w2;
+    if (!ok) { v[0] = v[1] = v[2] = NAN; }
+}
+
 // q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
 // base point and both forward-difference points).  M = N - q I with N >= 0.  When a state is
 // numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway rate
@@ -706,6 +732,7 @@ struct PairProblem {
     double P[2][3];        // pair-state vectors at the start of the interval
     double s[2];           // their sums
     double tgt[2];         // cpfit: exp(-lh_k) * s_k (:141); default fit: one-population expected coalescence time (:74-77)
+    int red;               // structural reduction of the pair generator for this interval (pair_reduced): 0 none, 1 / 2 state 0 / 1 empty and unfed
 };
 
 // One residual evaluation per lane: this lane's role r (= 2 e + k, see PairProblem) at ITS point (x0, x1).  The six
@@ -727,7 +754,8 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
     if (CPFIT) {
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
         for (int i = 0; i < 3; ++i) w[i] = k ? pb.P[1][i] : pb.P[0][i];
-        pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
+        if (pb.red != 0 && q + neg < 1e300) pair_reduced(pb.red, l0, l1, pb.mu0, pb.mu1, w, ok);
+        else pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
         res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
@@ -1184,6 +1212,10 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 const double lhs0 = lh0 * T, lhs1 = lh1 * T;
                 for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
                 pb.s[0] = s0; pb.s[1] = s1;
+                // "empty": below 1e-30 of the genome's total - what one interval with rate x length > 70 leaves; far below
+                // the rounding of every sum the state enters (it is dropped, not carried)
+                pb.red = !CPFIT ? 0 : (pb.mu1 == 0.0 && ps.p[0][0] <= PAIR_EMPTY * s0 && ps.p[1][0] <= PAIR_EMPTY * s1) ? 1
+                                    : (pb.mu0 == 0.0 && ps.p[0][1] <= PAIR_EMPTY * s0 && ps.p[1][1] <= PAIR_EMPTY * s1) ? 2 : 0;
                 if (uni<GROUP>(!pre || averaged)) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
                 if (CPFIT) { pb.tgt[0] = eh0 * s0; pb.tgt[1] = eh1 * s1; }
                 else {

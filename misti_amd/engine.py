@@ -21,6 +21,7 @@ device is present, construction fails loudly.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 import sys
 
@@ -103,12 +104,16 @@ class Engine:
         ctx = C.c_void_p()
         _lib.check(self._lib.misti_create(C.byref(m), int(device), C.byref(ctx)))
         self._ctx = ctx
+        self._pid = os.getpid()
         self.device = int(device)
 
     # -- lifetime --------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx:
-            self._lib.misti_destroy(self._ctx)
+            # a context belongs to the process that created it: in a child forked later (a worker pool of the caller)
+            # the HIP runtime is not usable - a garbage-collected copy of this object there must not call into it
+            if getattr(self, "_pid", None) == os.getpid():
+                self._lib.misti_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):

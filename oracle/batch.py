@@ -80,7 +80,10 @@ def oracle_batch(workload, indices, processes=1):
         res = [_worker((common, cands))]
     else:
         chunks = [cands[k::processes] for k in range(processes)]
-        with mp.get_context("fork").Pool(processes) as pool:
+        # The caller may hold GPU objects (engine contexts, device tensors): a forked child must never finalise its copies of
+        # them - HIP is unusable there - so the workers run without the cyclic collector (they live for one map() call).
+        import gc
+        with mp.get_context("fork").Pool(processes, initializer=gc.disable) as pool:
             res = pool.map(_worker, [(common, c) for c in chunks])
         # undo the striding
         merged = [None] * len(cands)

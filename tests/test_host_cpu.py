@@ -174,3 +174,29 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
         pytest.skip("a GPU is present: the run itself is tests/test_gpu_golden.py::test_c_example")
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+def test_engine_context_is_not_destroyed_from_another_process():
+    """A forked child (a caller's worker pool) may garbage-collect its copy of an Engine: that copy must not call into
+    the library - HIP is unusable in the child (this segfaulted a pool worker and hung the GPU test run once)."""
+    import ctypes as C
+    import os
+    from misti_amd.engine import Engine
+
+    class FakeLib:
+        def __init__(self):
+            self.destroyed = 0
+
+        def misti_destroy(self, ctx):
+            self.destroyed += 1
+
+    e = Engine.__new__(Engine)
+    e._lib = FakeLib()
+    e._ctx = C.c_void_p(1234)
+    e._pid = os.getpid() + 1                  # "created in another process"
+    e.close()
+    assert e._lib.destroyed == 0 and not e._ctx
+    e._ctx = C.c_void_p(1234)
+    e._pid = os.getpid()
+    e.close()
+    assert e._lib.destroyed == 1 and not e._ctx
