@@ -390,7 +390,8 @@ def sweep_cases():
 
 # the candidates of the random campaign (tools/random_campaign.py, seed 1, 600 models) on which the HIP path stands
 # worst against the ORACLE: every one outside the contract there, and the two largest factors inside it
-CAMPAIGN_PICKS = ((148, 12), (515, 0), (515, 2), (515, 4), (515, 6), (583, 3), (547, 2), (202, 0), (353, 0), (198, 1))
+CAMPAIGN_PICKS = ((1, 148, 12), (1, 515, 0), (1, 515, 2), (1, 515, 4), (1, 515, 6), (1, 583, 3), (1, 547, 2), (1, 202, 0), (1, 353, 0), (1, 198, 1),
+                  (2, 35, 1), (2, 35, 9), (2, 35, 11), (2, 35, 21))       # (campaign seed, model, candidate)
 
 
 def campaign_cases(kinds=32):
@@ -398,11 +399,13 @@ def campaign_cases(kinds=32):
     and solver traces: what the campaign measures against the oracle, measured against the reference."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from random_campaign import random_batch
-    rng = numpy.random.default_rng(1)
-    models = [random_batch(rng) for _ in range(600)]
+    models = {}
+    for seed in sorted({p[0] for p in CAMPAIGN_PICKS}):
+        rng = numpy.random.default_rng(seed)
+        models[seed] = [random_batch(rng) for _ in range(600)]
     out = []
-    for mi_, k in CAMPAIGN_PICKS:
-        c = models[mi_]
+    for seed, mi_, k in CAMPAIGN_PICKS:
+        c = models[seed][mi_]
         st = float(c["split"][k])
         end = int(st) + (1 if st % 1 else 0)
         par = [float(v) for v in c["params"][k]] if c["P"] else []
@@ -417,7 +420,7 @@ def campaign_cases(kinds=32):
         if c["sd"]:
             kw["sampleDate"] = c["sd"]
         split = int(st) if st % 1 == 0 else st
-        g = case("camp_m%d_c%d" % (mi_, k), c["times"], c["lh"], c["sfs"], split, mi, pu, par, **kw)
+        g = case(("camp_m%d_c%d" if seed == 1 else "camp_s%d_m%%d_c%%d" % seed) % (mi_, k), c["times"], c["lh"], c["sfs"], split, mi, pu, par, **kw)
         o = g["out"]
         if o["llh"] is not None:
             _, o["spread"], o["pert_fail"], o["pert_llh"] = perturbation_study(c["times"], c["lh"], c["sfs"], split, mi, pu, kw, par, o["llh"], kinds)
@@ -425,7 +428,7 @@ def campaign_cases(kinds=32):
             # kinds 0-2 and by 1.9e-10 under kind 17)
             o["sens"] = None if o["pert_fail"] else o["spread"] / PERTURB
         o.pop("Pr", None)
-        g["campaign"] = {"model": mi_, "cand": k}
+        g["campaign"] = {"seed": seed, "model": mi_, "cand": k}
         out.append(g)
     return out
 
