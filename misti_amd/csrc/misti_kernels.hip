@@ -354,6 +354,39 @@ __device__ __forceinline__ void solve3(const double M[3][3], const double b[3], 
     x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) * id;
 }
 
+// 3x3 solve by Gaussian elimination with partial pivoting (the order of LAPACK's getrf/getrs, which is what
+// scipy.linalg.inv does): unlike the cofactor form it never multiplies a structurally zero entry into a live one, so a
+// component of the solution that does not depend on some matrix entry mathematically does not depend on it bitwise
+// either - the reference's finite-difference Jacobian has exact zeros there and so must ours.
+__device__ __forceinline__ void solve3_ge(const double Min[3][3], const double b[3], double x[3]) {
+    double A[3][3], r[3];
+    for (int i = 0; i < 3; ++i) { r[i] = b[i]; for (int j = 0; j < 3; ++j) A[i][j] = Min[i][j]; }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        // pivot: largest magnitude in column c at or below the diagonal (first one on ties, as idamax)
+        int pv = c;
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) if (fabs(A[i][c]) > fabs(A[pv][c])) pv = i;
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) {
+            if (i == pv) {                                   // swap rows c and pv (selects: pv is data)
+                for (int j = 0; j < 3; ++j) { const double t = A[c][j]; A[c][j] = A[i][j]; A[i][j] = t; }
+                const double t = r[c]; r[c] = r[i]; r[i] = t;
+            }
+        }
+        const double piv = 1.0 / A[c][c];                    // getf2 scales the column by the reciprocal of the pivot
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) {
+            const double l = A[i][c] * piv;
+            for (int j = c + 1; j < 3; ++j) A[i][j] = A[i][j] - l * A[c][j];
+            r[i] = r[i] - l * r[c];
+        }
+    }
+    x[2] = r[2] / A[2][2];
+    x[1] = (r[1] - A[1][2] * x[2]) / A[1][1];
+    x[0] = ((r[0] - A[0][1] * x[1]) - A[0][2] * x[2]) / A[0][0];
+}
+
 // Reciprocal / square root for the solver's bookkeeping: hardware seed + Newton steps, ~1 ulp,
 // a third of the instructions of the correctly rounded forms (no denormal/overflow scaling:
 // every operand here is a normal-range quantity or the result is tested for finiteness anyway).
@@ -765,14 +798,23 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
         pair_expv<true>(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard, vint, &have_int);
         double pnc = (w[0] + w[1]) + w[2];
         double v0 = vint[0], v1 = vint[1];          // (vec2 - vec1) of the reference, T = 1 after the stretch
+#ifdef MISTI_ECT_FORMULA
+        have_int = false;
+#endif
         if (!have_int) {
             // stiff iterate (|M| > 1): the reference's own formula, M^-1 exp(M) pn - M^-2 (exp(M) - I) pn
             double M[3][3] = {{-2 * pb.mu0 - l0, 0.0, pb.mu1}, {0.0, -2 * pb.mu1 - l1, pb.mu0}, {2 * pb.mu0, 2 * pb.mu1, -pb.mu0 - pb.mu1}};
             double dd[3] = {w[0] - pn[0], w[1] - pn[1], w[2] - pn[2]};
             double y[3], vec1[3], vec2[3];
+#ifdef MISTI_ECT_FORMULA
+            solve3_ge(M, dd, y);
+            solve3_ge(M, y, vec1);
+            solve3_ge(M, w, vec2);
+#else
             solve3(M, dd, y);
             solve3(M, y, vec1);
             solve3(M, w, vec2);
+#endif
             v0 = vec2[0] - vec1[0]; v1 = vec2[1] - vec1[1];
         }
         double ect = (l0 * v0 + l1 * v1) / (1.0 - pnc);

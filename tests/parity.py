@@ -83,6 +83,26 @@ def perturbed(times, lambdas, kind):
     return T, L
 
 
+# ---- golden cases known to fall outside the contract, each with its measured distance as the bound -------------------
+# camp_m148_c12: the one candidate of campaign seed 1 that stays outside the contract against the reference itself (2.5e-7 where 160 input
+# perturbations of the reference move it by <= 1.5e-8 and one ulp in its expm by 1.2e-8): interval 28 is a runaway solve
+# (rate x length 1e5, 38 reference iterations) in which both sides walk the same points to ~1e-6 until, at iteration 23,
+# the reference's gain ratio is > 0.75 (radius doubled) and the HIP path's is not - numerator and denominator are both
+# rounding noise of a saturated residual there - and the two stop 8 iterations apart (profiles/r02_solver_traces.txt).
+# Kept as a test with its measured distance as the bound, reported as OUTSIDE by tools/parity_report.py.
+KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6,
+                 # Campaign seed 2, model 35 (default fit, one band over one interval): the chain's one migrating solve takes the
+                 # reference 3 evaluations and the HIP path 2 - (nfev 3) | (nfev 2) in profiles/r02_solver_traces.txt.  The
+                 # reference's residual M^-1 e^M p - M^-2 (e^M - I) p carries ~1e-14 of cancellation noise, its forward-difference
+                 # Jacobian (h = 1.5e-8) therefore ~1e-6, so its first Gauss-Newton step lands where |J^T f| is still above
+                 # gtol = 1e-10 and a third evaluation converges fully; the device's integral series has no such noise, its
+                 # first step already satisfies gtol and SciPy's test stops it there, 1e-7 short in the rate.  With the
+                 # reference's own formula on the device (-DMISTI_ECT_FORMULA) these four agree to 1e-11 ... 8e-11 - and 90 to
+                 # 120 other candidates per campaign move out to 1e-3 (its noise is then drawn twice): DESIGN.md section 2.
+                 "camp_s2_m35_c1": 5e-8, "camp_s2_m35_c9": 5e-8, "camp_s2_m35_c11": 5e-8, "camp_s2_m35_c21": 5e-8}
+
+
+
 def determined(out):
     return out.get("sens") is not None and out["sens"] < SENS_DETERMINED
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import JAFS_RTOL, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of
+from parity import JAFS_RTOL, KNOWN_OUTSIDE, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of
 
 pytestmark = pytest.mark.gpu
 
@@ -69,15 +69,6 @@ def test_synthetic(case):
 def test_sweep_one_by_one(case):
     """The README's four-band sweep, one model object per grid point as the reference runs it."""
     check(case)
-
-
-# The one candidate of the campaign that stays outside the contract against the reference itself (2.5e-7 where 160 input
-# perturbations of the reference move it by <= 1.5e-8 and one ulp in its expm by 1.2e-8): interval 28 is a runaway solve
-# (rate x length 1e5, 38 reference iterations) in which both sides walk the same points to ~1e-6 until, at iteration 23,
-# the reference's gain ratio is > 0.75 (radius doubled) and the HIP path's is not - numerator and denominator are both
-# rounding noise of a saturated residual there - and the two stop 8 iterations apart (profiles/r02_solver_traces.txt).
-# Kept as a test with its measured distance as the bound, reported as OUTSIDE by tools/parity_report.py.
-KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6}
 
 
 @pytest.mark.parametrize("case", CAMPAIGN, ids=[c["name"] for c in CAMPAIGN])

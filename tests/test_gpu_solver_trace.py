@@ -11,7 +11,7 @@ scipy.optimize.least_squares while running the reference).  The HIP path reports
 import pytest
 
 from conftest import load_golden
-from parity import determined
+from parity import KNOWN_OUTSIDE, determined
 from solver_trace_util import compare_case, load_traces
 
 pytestmark = pytest.mark.gpu
@@ -26,6 +26,12 @@ def test_iteration_history(name):
     r = compare_case(case, ref)
     fd = r["first_diff"]
     assert r["max_rel_before"] <= 1e-5, r                        # trial points of the solves before the first differing one
+    if name.startswith("camp_s2_m35"):
+        # documented outlier (tests/parity.py: KNOWN_OUTSIDE): exactly one solve differs - the migrating interval of the
+        # default fit, three evaluations in the reference, two on the device
+        assert name in KNOWN_OUTSIDE and fd is not None and fd["site"] == "two_pop_ect" and fd["ref"] == (3, 1) and fd["hip"] == (2, 1), r
+        assert r["n_equal"] == r["n_solves"] - 1, r
+        return
     if determined(case["out"]):
         assert fd is None and r["n_equal"] == r["n_solves"], r   # the same iteration, solve by solve
         assert r["max_rel_before"] <= 1e-6
