@@ -1,7 +1,7 @@
-"""Randomised differential campaign as a test: 2 x 600 random models (numT 8-40, all flag combinations, bands in both
+"""Randomised differential campaign as a test: 3 x 600 random models (numT 8-40, all flag combinations, bands in both
 directions, pulses, ancient sample, fractional splits), each evaluated as ONE batch of 6-28 candidates through the C
 ABI - so chains are shared and the trunk paths run - against the oracle's value of every candidate
-(tests/golden/campaign_seed{1,2}.json.gz, written by `tools/random_campaign.py --make-ref`; 27 minutes of oracle time
+(tests/golden/campaign_seed{1,2,3}.json.gz, written by `tools/random_campaign.py --make-ref`; 27 minutes of oracle time
 each, plus tools/self_perturbation.py's studies of the oracle's own spread)."""
 import os
 import sys
@@ -14,7 +14,7 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,n_expected", [(1, 7648), (2, 7694)])
+@pytest.mark.parametrize("seed,n_expected", [(1, 7648), (2, 7694), (3, 7434)])
 def test_random_batches_against_the_oracle(seed, n_expected):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import random_campaign as rc
@@ -28,11 +28,11 @@ def test_random_batches_against_the_oracle(seed, n_expected):
     # failure against value only where the reference itself flips under a 2^-48 perturbation
     assert s["status_mismatch"] <= 3, rep["bad"][:5]
     comparable = s["tight"] + s["self_bound"] + s["internal_bound"] + s["outside"]
-    assert comparable >= 7000
+    assert comparable >= n_expected - 700                  # the rest fails on both sides (negative rates, failed corrections)
     # the contract per candidate (tests/parity.py): 1e-9 (+ rounding floor), or 10 x the reference's own spread under 4-64
     # perturbations of 2^-48 for THAT candidate, or (the 162 candidates beyond twice that spread were studied) under one
     # ulp in its own pair-chain expm (tests/golden/campaign_seed1.json.gz, tools/self_perturbation.py)
-    assert s["tight"] >= 5000
+    assert s["tight"] >= 0.70 * comparable
     # Discrete stop/continue flips of SciPy's tests are rare events of the reference too (a few per thousand
     # ill-conditioned solves): a candidate whose flip the 4-64 perturbed reference runs did not happen to sample lands
     # outside.  The fixture was studied against one build; another rounding realisation moves which candidates those are,
