@@ -1496,8 +1496,11 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     }
 }
 
+#ifndef MISTI_DEFAULT_FIT_WAVES
+#define MISTI_DEFAULT_FIT_WAVES 1
+#endif
 template <bool CPFIT, int GROUP>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPFIT ? 2 : MISTI_DEFAULT_FIT_WAVES, CPFIT ? 2 : MISTI_DEFAULT_FIT_WAVES)))
 void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
     extern __shared__ double lds[];
     {   // candidate -> chain, once, by blocks that mostly have nothing else to do (the launch has one block per
