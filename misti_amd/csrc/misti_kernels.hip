@@ -265,6 +265,42 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         { double nrm = 2.0 * nbmax; while (nrm > 0.25) { nrm *= 0.5; ++sq; } }
         dg.dense += 1; dg.squarings += sq;
         double scl = ldexp(1.0, -sq);
+        if (mu1 == 0.0) {
+            // Migration out of population 0 only: the generator is triangular in the order (0, 2, 1), exp(M) has the six
+            // entries E00, E11, E22, E20 (0 -> 2), E12 (2 -> 1), E10 (0 -> 2 -> 1) and exact zeros elsewhere - in the full
+            // 3x3 arithmetic below too, where every product with one of them is +-0 and every sum absorbs it.  Leaving
+            // those products out (fused forms spelt as the compiler contracts the full expressions) gives the same bits
+            // with 9 + 10 products per Horner step / squaring instead of 21 + 27.
+            const double B00 = -d0 * scl, B11 = -d1 * scl, B12 = mu0 * scl, B20 = 2.0 * mu0 * scl, B22 = -d2 * scl;
+            const double i12 = c_inv[12];
+            double t00 = B00 * i12, t11 = B11 * i12, t22 = B22 * i12;
+            double E00 = t00 + 1.0, E11 = t11 + 1.0, E22 = t22 + 1.0, E12 = B12 * i12 + 0.0, E20 = B20 * i12 + 0.0, E10 = 0.0;
+            for (int k = 11; k >= 1; --k) {
+                const double inv = c_inv[k];
+                const double n00 = (B00 * E00) * inv;
+                const double n10 = fma(B12, E20, B11 * E10) * inv;
+                const double n11 = (B11 * E11) * inv;
+                const double n12 = fma(B12, E22, B11 * E12) * inv;
+                const double n20 = fma(B22, E20, B20 * E00) * inv;
+                const double n22 = (B22 * E22) * inv;
+                E00 = n00 + 1.0; E10 = n10 + 0.0; E11 = n11 + 1.0; E12 = n12 + 0.0; E20 = n20 + 0.0; E22 = n22 + 1.0;
+            }
+            for (int i = 0; i < sq; ++i) {
+                const double n00 = E00 * E00;
+                const double n10 = fma(E12, E20, fma(E10, E00, E11 * E10));
+                const double n11 = E11 * E11;
+                const double n12 = fma(E12, E22, E11 * E12);
+                const double n20 = fma(E22, E20, E20 * E00);
+                const double n22 = E22 * E22;
+                E00 = n00; E10 = n10; E11 = n11; E12 = n12; E20 = n20; E22 = n22;
+            }
+            const double w0 = E00 * v[0];
+            const double w1 = fma(E12, v[2], fma(E10, v[0], E11 * v[1]));
+            const double w2 = fma(E22, v[2], E20 * v[0]);
+            v[0] = w0; v[1] = w1; v[2] = w2;
+            if (!ok) { v[0] = v[1] = v[2] = NAN; }
+            return;
+        }
         double B[3][3] = {{-d0 * scl, 0.0, mu1 * scl}, {0.0, -d1 * scl, mu0 * scl}, {2.0 * mu0 * scl, 2.0 * mu1 * scl, -d2 * scl}};
         // Horner, E = I + B E / k for k = 12 .. 1.  The first step (E = I) is B / 12 + I; B[0][1] = B[1][0] = 0 are left out
         // of the products - with the fused forms spelt out both give the bits of the full 3x3 product for finite entries.
