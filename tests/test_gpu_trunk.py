@@ -163,3 +163,33 @@ def test_chains_per_wave_do_not_change_results():
         assert_identical(out["1"][0], out[cpw][0])
         assert_identical(out["1"][1], out[cpw][1])
     assert (out["1"][0].status == 0).mean() > 0.9
+
+
+def test_speculation_and_reduction_do_not_change_results():
+    """The headline grid (one-way migration, runaway rates: the rank-one regime) through the one-chain-per-wave kernel -
+    speculation tree, bookkeeping of all hypotheses at once, following trunk - and through the packed kernels (4 and 10
+    chains per wave: no speculation, trunks afterwards): every candidate's llk, spectrum, rates, pair states and status
+    bit for bit the same.  (MISTI_CHAINS_PER_WAVE is the diagnostic override of the launch shape.)"""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a))
+    out = {}
+    for cpw in ("1", "4", "10"):
+        os.environ["MISTI_CHAINS_PER_WAVE"] = cpw
+        try:
+            with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+                e.evaluate(w.split_time, w.params, w.jsfs)                 # the launch shape follows the previous batch's chain count
+                out[cpw] = e.evaluate(w.split_time, w.params, w.jsfs, want_lc=True, want_pr=True)
+        finally:
+            os.environ.pop("MISTI_CHAINS_PER_WAVE", None)
+    a = out["1"]
+    assert (a.status == 0).all()
+    spec = a.pr[:, -1, 3]                                                   # work counters: solver steps taken from speculative slots
+    assert spec.max() > 100 and (out["10"].pr[:, -1, 3] == 0).all()         # the first really speculated, the packed one did not
+    for cpw in ("4", "10"):
+        b = out[cpw]
+        assert np.array_equal(a.status, b.status)
+        for name in ("llk", "jafs", "lc"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert np.array_equal(x, y, equal_nan=True), (cpw, name, float(np.nanmax(np.abs(x - y))))
+        assert np.array_equal(a.pr[:, :-1, :], b.pr[:, :-1, :], equal_nan=True), cpw   # pair-state trace (last row: counters)
