@@ -798,9 +798,11 @@ __device__ __forceinline__ double ect_noncond(double lam, double T) { return (1.
 // lane (within the group) = 2*e + k: e = 0 base, 1 = x + h0 e0, 2 = x + h1 e1; k = genome.
 struct PairProblem {
     double mu0, mu1;       // stretched to unit interval (CorrectLambda.py:293-298)
-    double P[2][3];        // pair-state vectors at the start of the interval
-    double s[2];           // their sums
-    double tgt[2];         // cpfit: exp(-lh_k) * s_k (:141); default fit: one-population expected coalescence time (:74-77)
+    // of THIS lane's genome k = role & 1 (a lane evaluates one genome for as long as it lives: keeping only its own row
+    // halves what the solver loop carries)
+    double Pk[3];          // pair-state vector at the start of the interval
+    double sk;             // its sum
+    double tgtk;           // cpfit: exp(-lh_k) * s_k (:141); default fit: one-population expected coalescence time (:74-77)
     int red;               // structural reduction of the pair generator for this interval (pair_reduced): 0 none, 1 / 2 state 0 / 1 empty and unfed
 };
 
@@ -819,18 +821,18 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
     const double m0 = fmax(x0, xa), m1 = fmax(x1, xb);
     const double q = fmax(fmax(2.0 * pb.mu0 + m0, 2.0 * pb.mu1 + m1), fmax(pb.mu0 + pb.mu1, 0.0));
     const double neg = fmax(0.0, fmax(-fmin(x0, xa), -fmin(x1, xb)));
-    const double sk = k ? pb.s[1] : pb.s[0];
+    const double sk = pb.sk;
     if (CPFIT) {
         // LambdaSystem1 / LambdaEquation, CorrectLambda.py:135-144,169-173
-        for (int i = 0; i < 3; ++i) w[i] = k ? pb.P[1][i] : pb.P[0][i];
+        for (int i = 0; i < 3; ++i) w[i] = pb.Pk[i];
         if (pb.red != 0 && q + neg < 1e300) pair_reduced(pb.red, l0, l1, pb.mu0, pb.mu1, w, ok);
         else pair_expv(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard);
-        res = ((w[0] + w[1]) + w[2]) - (k ? pb.tgt[1] : pb.tgt[0]);
+        res = ((w[0] + w[1]) + w[2]) - pb.tgtk;
     } else {
         // LambdaSystem / ExpectedCoalTimeTwoPop, CorrectLambda.py:94-110,151-157
         double pn[3], vint[3] = {0.0, 0.0, 0.0};
         bool have_int = false;
-        for (int i = 0; i < 3; ++i) { pn[i] = (k ? pb.P[1][i] : pb.P[0][i]) / sk; w[i] = pn[i]; }
+        for (int i = 0; i < 3; ++i) { pn[i] = pb.Pk[i] / sk; w[i] = pn[i]; }
         pair_expv<true>(l0, l1, pb.mu0, pb.mu1, w, q, neg, ok, dg, guard, vint, &have_int);
         double pnc = (w[0] + w[1]) + w[2];
         double v0 = vint[0], v1 = vint[1];          // (vec2 - vec1) of the reference, T = 1 after the stretch
@@ -854,7 +856,7 @@ __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, doub
             v0 = vec2[0] - vec1[0]; v1 = vec2[1] - vec1[1];
         }
         double ect = (l0 * v0 + l1 * v1) / (1.0 - pnc);
-        res = ect - (k ? pb.tgt[1] : pb.tgt[0]);
+        res = ect - pb.tgtk;
         // the state vector handed on is exp(M) applied to the unnormalised vector
         w[0] *= sk; w[1] *= sk; w[2] *= sk;
     }
@@ -920,7 +922,7 @@ __device__ __forceinline__ double predicted_of(const double J[2][2], const doubl
 // otherwise the regularised step from the SVD.  Returns the predicted reduction.
 template <int GROUP>
 __device__ __forceinline__ double next_step(const double J[2][2], const double f[2], const double g[2], double Delta, double& alpha,
-                                            Svd2& sv, bool& have_sv, double p[2], int& lm, int& axis) {
+                                            double p[2], int& lm, int& axis) {
     const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
     const double F = (J[0][0] * J[0][0] + J[0][1] * J[0][1]) + (J[1][0] * J[1][0] + J[1][1] * J[1][1]);
     // A structurally decoupled rate (Jacobian column exactly zero, see pair_expv): J has rank one,
@@ -945,8 +947,10 @@ __device__ __forceinline__ double next_step(const double J[2][2], const double f
         p[1] = rank1 ? (z0 ? pk : 0.0) : p1;
         alpha = 0.0;
     } else {
-        if (!have_sv) { sv = svd_mx2<2>(J, f); have_sv = true; }
-        solve_tr(sv, 2, Delta, alpha, p);
+        // the decomposition is recomputed on every regularised step (rejected steps repeat it for the same J, f: ~50 such
+        // steps per chain) rather than carried through the solver loop: 16 registers of loop-carried state less
+        const Svd2 d = svd_mx2<2>(J, f);
+        solve_tr(d, 2, Delta, alpha, p);
         lm += 1;
     }
     return predicted_of(J, p, g);
@@ -1168,8 +1172,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     double x[2] = {0, 0}, f[2] = {0, 0}, J[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0}, xe[2] = {0, 0}, p[2] = {0, 0}, vk[3] = {0, 0, 0};
     double cost = 0.0, Delta = 0.0, alpha = 0.0, predicted = 0.0;
     int nfev = 0;
-    bool first = false, in_solve = false, have_sv = false;
-    Svd2 sv;
+    bool first = false, in_solve = false;
     // speculative slots (one chain per wave only): SPEC_SLOTS x 6 lanes, slot 0 = the point the solver asked for
 #ifndef MISTI_SPEC
 #define MISTI_SPEC 1
@@ -1288,21 +1291,23 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 if (uni<GROUP>(nd < 0.0004 * fmin(n0, n1))) { double mean = (lh0 + lh1) / 2.0; lh0 = lh1 = mean; averaged = true; }   // normD < 0.02 min(norms), squared
                 pb.mu0 = mu0 * T; pb.mu1 = mu1 * T;                                      // stretch :293-298
                 const double lhs0 = lh0 * T, lhs1 = lh1 * T;
-                for (int k = 0; k < 2; ++k) for (int i = 0; i < 3; ++i) pb.P[k][i] = ps.p[k][i];
-                pb.s[0] = s0; pb.s[1] = s1;
+                const bool g1 = role & 1;                                                // this lane's genome
+                for (int i = 0; i < 3; ++i) pb.Pk[i] = g1 ? ps.p[1][i] : ps.p[0][i];
+                pb.sk = g1 ? s1 : s0;
                 // "empty": below 1e-30 of the genome's total - what one interval with rate x length > 70 leaves; far below
                 // the rounding of every sum the state enters (it is dropped, not carried)
                 pb.red = !CPFIT ? 0 : (pb.mu1 == 0.0 && ps.p[0][0] <= PAIR_EMPTY * s0 && ps.p[1][0] <= PAIR_EMPTY * s1) ? 1
                                     : (pb.mu0 == 0.0 && ps.p[0][1] <= PAIR_EMPTY * s0 && ps.p[1][1] <= PAIR_EMPTY * s1) ? 2 : 0;
                 if (uni<GROUP>(!pre || averaged)) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
-                if (CPFIT) { pb.tgt[0] = eh0 * s0; pb.tgt[1] = eh1 * s1; }
+                if (CPFIT) { const double t0_ = eh0 * s0, t1_ = eh1 * s1; pb.tgtk = g1 ? t1_ : t0_; }
                 else {
                     double pa = eh0, pbb = eh1;                                          // ExpectedCoalTimeOnePopTmp, T = 1
-                    pb.tgt[0] = 1.0 / lhs0 - 1.0 / (1.0 / pa - 1.0);
-                    pb.tgt[1] = 1.0 / lhs1 - 1.0 / (1.0 / pbb - 1.0);
+                    const double t0_ = 1.0 / lhs0 - 1.0 / (1.0 / pa - 1.0);
+                    const double t1_ = 1.0 / lhs1 - 1.0 / (1.0 / pbb - 1.0);
+                    pb.tgtk = g1 ? t1_ : t0_;
                 }
                 xe[0] = lhs0; xe[1] = lhs1;
-                first = true; in_solve = true; have_sv = false; spec_axis = -1;
+                first = true; in_solve = true; spec_axis = -1;
                 break;
             }
             if (uni<GROUP>(!in_solve)) { active = false; break; }  // reached the split, or failed
@@ -1428,7 +1433,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) J[r][c] = bcast(Js[r][c], at);
                 cost = bcast(cs, at);
                 Delta = bcast(Dl, at);
-                if (last_acc >= 0) { vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2]; vk_base = 6 * last_acc; have_sv = false; }
+                if (last_acc >= 0) { vk[0] = w[0]; vk[1] = w[1]; vk[2] = w[2]; vk_base = 6 * last_acc; }
                 g[0] = J[0][0] * f[0] + J[1][0] * f[1];
                 g[1] = J[0][1] * f[0] + J[1][1] * f[1];
                 // the step after a consumed slot is again the rank-one one along k (that is what its outcome code says):
@@ -1491,7 +1496,6 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             vk_base = accept ? base : vk_base;           // the lanes whose state vectors belong to the accepted point
             g[0] = J[0][0] * f[0] + J[1][0] * f[1];
             g[1] = J[0][1] * f[0] + J[1][1] * f[1];
-            have_sv = have_sv && !accept;
             STAMP(c_update)
             if (term != 0) done = true;
             else if (accept) {
@@ -1507,7 +1511,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 if (uni<GROUP>(!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3)))) { active = false; stop = true; }   // :312, :346-348
                 break;
             }
-            predicted = next_step<GROUP>(J, f, g, Delta, alpha, sv, have_sv, p, dg.lm, spec_axis);
+            predicted = next_step<GROUP>(J, f, g, Delta, alpha, p, dg.lm, spec_axis);
             xe[0] = x[0] + p[0]; xe[1] = x[1] + p[1];
             STAMP(c_next)
             if (!SPEC) break;
