@@ -1096,7 +1096,7 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 // (trial point + its forward-difference points) + the trust-region bookkeeping of
 // trf_no_bounds (trf.py:401-560), so the items of a wavefront never wait for each other
 // interval by interval.
-template <bool CPFIT, int GROUP, bool TAIL>
+template <bool CPFIT, int GROUP, bool TAIL, bool PRE = false>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
                   int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr) {
@@ -1168,7 +1168,6 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 
     // solver state of the interval in progress
     PairProblem pb;
-    double T = 0.0;
     double x[2] = {0, 0}, f[2] = {0, 0}, J[2][2] = {{0, 0}, {0, 0}}, g[2] = {0, 0}, xe[2] = {0, 0}, p[2] = {0, 0}, vk[3] = {0, 0, 0};
     double cost = 0.0, Delta = 0.0, alpha = 0.0, predicted = 0.0;
     int nfev = 0;
@@ -1211,7 +1210,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 #define STAMP(acc)
 #endif
     bool active = status == MISTI_OK;
-    if (pre) {
+    if (PRE) {
         // What an interval needs that does not depend on the recursion - migration rates, pulse, exp(-lh T) of both
         // genomes - for all intervals at once, one interval per lane, instead of a band-table walk and two exponentials on
         // the critical path of every interval.  Same expressions as below, so the same bits.
@@ -1234,12 +1233,12 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             // ---- advance over intervals until one needs the iterative solver ----------
             while (uni<GROUP>(t < G.split)) {
                 double pu0, pu1, mu0, mu1, eh0 = 0.0, eh1 = 0.0;
-                if (pre) { const double* q = pre + 6 * t; mu0 = q[0]; mu1 = q[1]; pu0 = q[2]; pu1 = q[3]; eh0 = q[4]; eh1 = q[5]; }
+                if (PRE) { const double* q = pre + 6 * t; mu0 = q[0]; mu1 = q[1]; pu0 = q[2]; pu1 = q[3]; eh0 = q[4]; eh1 = q[5]; }
                 else { mod.pulse(t, pu0, pu1); mod.mig(t, mu0, mu1); }
                 pulse_pairs<GROUP>(ps, pu0, pu1);                                       // :315-323
                 double lh0 = G.lhk(t, 0), lh1 = G.lhk(t, 1);
                 if (!correct) { if (uni<GROUP>(!finish_interval(lh0, lh1, 0))) break; continue; }    // :325-326
-                T = G.T(t);
+                const double T = G.T(t);
                 const double s0 = (ps.p[0][0] + ps.p[0][1]) + ps.p[0][2];
                 const double s1 = (ps.p[1][0] + ps.p[1][1]) + ps.p[1][2];
                 if (m.mixture_th > 0.0) {                                               // CorrectLambda.py:267-272 (threshold 0 never fires)
@@ -1256,7 +1255,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                         double C1 = ps.p[0][2] / s0, C2 = ps.p[1][2] / s1;
                         double D = A1 * A4 - A2 * A3;
                         double B1 = A4 / D, B2 = -A2 / D, B3 = -A3 / D, B4 = A1 / D;
-                        if (!pre) { eh0 = exp(-lh0 * T); eh1 = exp(-lh1 * T); }
+                        if (!PRE) { eh0 = exp(-lh0 * T); eh1 = exp(-lh1 * T); }
                         double X1 = eh0 - C1, X2 = eh1 - C2;
                         double y0 = B1 * X1 + B2 * X2, y1 = B3 * X1 + B4 * X2;
                         if (uni<GROUP>(y0 > 0 && y1 > 0)) { lc0 = -log(y0) / T; lc1 = -log(y1) / T; }
@@ -1298,7 +1297,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 // the rounding of every sum the state enters (it is dropped, not carried)
                 pb.red = !CPFIT ? 0 : (pb.mu1 == 0.0 && ps.p[0][0] <= PAIR_EMPTY * s0 && ps.p[1][0] <= PAIR_EMPTY * s1) ? 1
                                     : (pb.mu0 == 0.0 && ps.p[0][1] <= PAIR_EMPTY * s0 && ps.p[1][1] <= PAIR_EMPTY * s1) ? 2 : 0;
-                if (uni<GROUP>(!pre || averaged)) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
+                if (uni<GROUP>(!PRE || averaged)) { eh0 = exp(-lhs0); eh1 = exp(-lhs1); }
                 if (CPFIT) { const double t0_ = eh0 * s0, t1_ = eh1 * s1; pb.tgtk = g1 ? t1_ : t0_; }
                 else {
                     double pa = eh0, pbb = eh1;                                          // ExpectedCoalTimeOnePopTmp, T = 1
@@ -1508,6 +1507,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 in_solve = false;
                 // OptimizeResult.status: the termination test that fired, 1 = gtol, 0 = evaluation budget (trf.py:452-456,556-558)
                 const int code = term != 0 ? term : ((accept && fmax(fabs(g[0]), fabs(g[1])) < LSQ_GTOL) ? 1 : 0);
+                const double T = G.T(t);               // re-read (LDS) rather than carried through the solver loop
                 if (uni<GROUP>(!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3)))) { active = false; stop = true; }   // :312, :346-348
                 break;
             }
@@ -1890,7 +1890,7 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
         if (threadIdx.x == 0) { lds_put(flags, 0); lds_put(flags + 1, 0); }
         __syncthreads();
         if (threadIdx.x < 64) {
-            correct_body<CPFIT, 64, false>(m, n_items, cb, split_time, params, ch, lds, lc_sh, flags, pre);
+            correct_body<CPFIT, 64, false, true>(m, n_items, cb, split_time, params, ch, lds, lc_sh, flags, pre);
             lds_order();
             if (threadIdx.x == 0) lds_put(flags + 1, 1);                     // whatever way the chain ended
         } else {
