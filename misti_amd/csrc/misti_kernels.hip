@@ -813,7 +813,7 @@ template <bool CPFIT>
 __device__ __forceinline__ void pair_eval(const PairProblem& pb, double x0, double x1, int role, Diag& dg, double& res, double w[3], bool& guard) {
     const double h0 = fd_step(x0), h1 = fd_step(x1);
     const double xa = x0 + h0, xb = x1 + h1;
-    const int e = role >> 1, k = role & 1;
+    const int e = role >> 1;
     const double l0 = (e == 1) ? xa : x0;
     const double l1 = (e == 2) ? xb : x1;
     const bool ok = isfinite(x0) && isfinite(x1);
