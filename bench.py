@@ -48,9 +48,9 @@ sys.path.insert(0, ROOT)
 # one-to-one onto hardware queues up to 24 queues per process; one queue more and the driver time-slices
 # them (throughput collapses 2x).  22 lanes is the single-process peak; defaults leave room for the null
 # stream and, with several ranks, for RCCL's and torch's own streams.
-# (single rank with RCCL initialised and the per-batch all_gather: best at 18-19 lanes, slowly worse beyond -> 16
-# with several ranks)
-DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 16
+# (single rank with RCCL initialised and one all_gather per 8 batches of a lane: 16 lanes 2.76e7, 18 lanes 2.86e7,
+# 20 lanes 2.65e7, 22 lanes 2.80e7 evals/s against 2.97e7 without RCCL -> 18 with several ranks)
+DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 18
 HW_QUEUES = 24
 HW_QUEUE_SLACK = 4
 
@@ -88,6 +88,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all_gather path even with one rank (rehearsal)")
+    ap.add_argument("--gather-bucket", type=int, default=8,
+                    help="multi-GPU: batches of a lane whose llk share ONE all_gather (fewer, larger collectives: xGMI is latency-bound at 32 KB)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES (default: %d)" % HW_QUEUES)
     ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
@@ -208,7 +210,7 @@ def main():
     d_split = torch.as_tensor(w.split_time[mine], dtype=torch.float64, device=dev)
     d_par = torch.as_tensor(w.params[mine], dtype=torch.float64, device=dev).contiguous() if P else None
     d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
-    d_all = torch.empty((world * per, R), dtype=torch.float64, device=dev) if use_dist else None
+    bucket = max(1, a.gather_bucket) if use_dist else 1
 
     torch.cuda.synchronize()                          # inputs have landed before any lane (non-blocking streams) reads them
 
@@ -221,20 +223,33 @@ def main():
         def __init__(self):
             self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
             self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
-            self.llk = torch.full((per, R), float("nan"), dtype=torch.float64, device=dev)     # rows beyond n: padding of a ragged shard
+            # multi-GPU: the llk of `bucket` consecutive batches of this lane are gathered by ONE collective (a 32 KB all_gather
+            # per batch is pure latency on xGMI and costs a fifth of the rate); every batch's llk still reaches every rank
+            self.slots = torch.full((bucket, per, R), float("nan"), dtype=torch.float64, device=dev)   # rows beyond n: padding of a ragged shard
+            self.gathered = torch.empty((world * bucket * per, R), dtype=torch.float64, device=dev) if use_dist else None
+            self.fill = 0
+            self.llk = self.slots[0]
             self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
             self.status = torch.empty(n, dtype=torch.int32, device=dev)
 
         def step(self):
+            self.llk = self.slots[self.fill]
             self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
                                   self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
             if use_dist:
-                # the batch's collective, issued from the lane's own stream: c10d orders it after the batch (event
-                # on this stream), runs it on its communicator stream in host issue order - the same on every rank -
-                # and makes this stream wait for it, so the next batch of the lane cannot overwrite llk early.
-                # (A dedicated communication stream + events per step cost a hardware queue and 15 % of the rate.)
+                self.fill += 1
+                if self.fill == bucket:
+                    self.flush()
+
+        def flush(self):
+            """The bucket's collective, issued from the lane's own stream: c10d orders it after the batches (event on this
+            stream), runs it on its communicator stream in host issue order - the same on every rank - and makes this
+            stream wait for it, so the next batch of the lane cannot overwrite a slot early.  (A dedicated communication
+            stream + events per step cost a hardware queue and 15 % of the rate.)  A partly filled bucket is gathered whole."""
+            if use_dist and self.fill > 0:
                 with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(d_all, self.llk)
+                    dist.all_gather_into_tensor(self.gathered, self.slots.view(bucket * per, R))
+                self.fill = 0
 
     def fence():
         if use_dist:
@@ -249,6 +264,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(steps):
             lanes[i % len(lanes)].step()
+        for lane in lanes:                           # what is still in a bucket belongs to the timed steps
+            lane.flush()
         host_issue[0] = time.perf_counter() - t0
         fence()
         dt = time.perf_counter() - t0
@@ -263,6 +280,8 @@ def main():
         min_seconds (at least once, at most 200 times; every rank takes the same decision: dt is the all-reduced max)."""
         for i in range(warmup):
             lanes[i % len(lanes)].step()
+        for lane in lanes:
+            lane.flush()
         dts = []
         while not dts or (sum(dts) < min_seconds and len(dts) < 200):
             dts.append(timed(lanes, steps))
@@ -321,8 +340,9 @@ def main():
         "config": {"workload": w.name, "candidates_per_gpu": n, "candidates_total": job_cands, "replicates": R, "numT": w.numT,
                    "batches_in_flight": n_streams, "streams": n_streams,
                    "world_size": group_world, "candidates_per_rank": cands_per_rank, "chains_per_rank": chains_per_rank,
-                   "parallelism": ("ONE grid sharded over the ranks (interleaved), all_gather of llk (RCCL)" if strong else
-                                   "every rank its own grid, all_gather of llk (RCCL)") if world > 1 else "1 GPU"},
+                   "gather_bucket": bucket if use_dist else None,
+                   "parallelism": ("ONE grid sharded over the ranks (interleaved), all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket if strong else
+                                   "every rank its own grid, all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket) if world > 1 else "1 GPU"},
         "timing": {"repeats": len(dts), "timed_region_s_median": dt, "timed_region_s_total": sum(dts),
                    "timed_region_s_min": min(dts), "timed_region_s_max": max(dts),
                    "note": "value and ms_per_step are the MEDIAN repetition of the K-step timed region (each between barriers, max over ranks)"},
