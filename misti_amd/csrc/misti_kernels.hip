@@ -1321,8 +1321,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         // (tests/golden/golden_traces.json.gz) - and the same again one level down.  The tree of those successors
         //        slot 0  the trial                     1, 2  0 accepted, doubled, then + / -        3  0 rejected
         //        4, 5    1 / 2 rejected                6, 7  3 accepted, doubled, then + / -        8  3 rejected
+        //        9       6 rejected (the likeliest third step: rejected, accepted +, rejected)
         // is evaluated in the idle lanes (slot s = lanes 6 s .. 6 s + 5) by the same pure function of the point, and the
-        // bookkeeping of all of them is then done at once, one hypothesis per slot (tree consume below): up to three
+        // bookkeeping of all of them is then done at once, one hypothesis per slot (tree consume below): up to four
         // solver steps per pass, bit for bit the same iteration.  A guess never consumed costs nothing.
         double px0 = xe[0], px1 = xe[1];
         const bool tree = SPEC && uni<GROUP>(spec_axis >= 0 && !first);       // wave-uniform
@@ -1338,13 +1339,15 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             const double xk = k == 0 ? x[0] : x[1], xek = k == 0 ? xe[0] : xe[1];
             const double u = xk + (pos ? dq0 : -dq0);                         // slot 3's point
             const int sl = slot_of_lane;
-            const bool root = sl == 0 || sl == 3 || sl == 8 || sl == 9;       // hypotheses that keep the current point x
-            Dpre_l = sl == 0 || sl == 9 ? Delta : sl <= 2 ? D2 : sl == 3 ? dq0 : sl <= 5 ? dq1 : sl <= 7 ? 2.0 * dq0 : dq3;
-            const bool pos_l = root ? pos : (sl == 1 || sl == 4 || sl == 6);
-            ps_l = (sl == 0 || sl == 9) ? pk : (pos_l ? Dpre_l : -Dpre_l);
-            const double from = root ? xk : (sl == 6 || sl == 7) ? u : xek;
+            const double dq0x2 = 2.0 * dq0;
+            const double dq6 = 0.25 * sqrt64(dq0x2 * dq0x2);                  // ... after rejecting, accepting the retry, doubling, rejecting
+            const bool root = sl == 0 || sl == 3 || sl == 8;                  // hypotheses that keep the current point x
+            Dpre_l = sl == 0 ? Delta : sl <= 2 ? D2 : sl == 3 ? dq0 : sl <= 5 ? dq1 : sl <= 7 ? dq0x2 : sl == 8 ? dq3 : dq6;
+            const bool pos_l = root ? pos : (sl == 1 || sl == 4 || sl == 6 || sl == 9);
+            ps_l = sl == 0 ? pk : (pos_l ? Dpre_l : -Dpre_l);
+            const double from = root ? xk : (sl == 6 || sl == 7 || sl == 9) ? u : xek;
             const double at = from + ps_l;
-            if (sl >= 1 && sl <= 8) { px0 = k == 0 ? at : xe[0]; px1 = k == 1 ? at : xe[1]; }
+            if (sl >= 1 && sl <= 9) { px0 = k == 0 ? at : xe[0]; px1 = k == 1 ? at : xe[1]; }
         }
         double res, w[3];
         bool guard_l = false;
@@ -1368,7 +1371,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             double xp[2], fp[2], Jp[2][2], cp;
             {
                 const bool lend = lane == 60;
-                const int src = (sl == 1 || sl == 2 || sl == 4 || sl == 5) ? 0 : (sl == 6 || sl == 7) ? 18 : 60;
+                const int src = (sl == 1 || sl == 2 || sl == 4 || sl == 5) ? 0 : (sl == 6 || sl == 7 || sl == 9) ? 18 : 60;
                 fp[0] = __shfl(lend ? f[0] : fnl[0], src, 64); fp[1] = __shfl(lend ? f[1] : fnl[1], src, 64);
                 for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) Jp[r][c] = __shfl(lend ? J[r][c] : Jnl[r][c], src, 64);
                 cp = __shfl(lend ? cost : cnl, src, 64);
@@ -1422,6 +1425,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 else if (cur == 1) child = code == 3 ? 4 : -1;
                 else if (cur == 2) child = code == 3 ? 5 : -1;
                 else if (cur == 3) child = code == 1 ? 6 : code == 2 ? 7 : 8;
+                else if (cur == 6) child = code == 3 ? 9 : -1;
                 if (child < 0) break;
                 cur = child;
             }
