@@ -6,6 +6,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
+Started WITHOUT torchrun and with --gpus N > 1 (no WORLD_SIZE in the environment) this process never touches the
+GPU: it starts the second command line as a child (one rank per GPU), forwards rank 0's single JSON line and
+exits with the child's code (`launch_ranks`).
+
 A step = one pass of the hot path (prepare, chain discovery, lambda-correction of the chains
 with their trunks following, tails, spectrum kernel with the replicate epilogue) over one
 batch: the 4 096-point grid of config 2 (64 split indices x 64 rates of one band
@@ -74,26 +78,64 @@ _early_streams()
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak
+GPU_CLOCK_HZ = 2.4e9           # MI355X peak engine clock (MI355X_MICROARCH.md)
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--workload", default="config2", help="config2 (headline) | config3 | config4 | config5 | config3-search")
+    ap.add_argument("--workload", default="config2",
+                    help="config2 (headline) | config2x16 | config3 | config4 | config5 | config3-search | config3-basinhopping")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="weak: every rank its own grid; strong: ONE grid sharded over the ranks (config4 / config5)")
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed loop until the timed regions add up to this; the median is reported")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the single_call / host_abi / strong blocks (headline leg only)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all_gather path even with one rank (rehearsal)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU (tests/test_bench_launcher_cpu.py): ranks rendezvous over gloo, shard a stub grid with "
+                         "misti_amd.dist and gather it; no engine, no measurement - the line says \"data\": \"dry-run\"")
     ap.add_argument("--gather-bucket", type=int, default=8,
                     help="multi-GPU: batches of a lane whose llk share ONE all_gather (fewer, larger collectives: xGMI is latency-bound at 32 KB)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES (default: %d)" % HW_QUEUES)
     ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port when this process starts the ranks itself (default: a free one)")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` as the driver invokes it: start N ranks as CHILD processes (torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1) and forward rank 0's JSON line.  This process has not imported torch or touched HIP and
+    never does - a process that has initialised the GPU must not be replaced or forked (the reference's counterpart is
+    `parallel -j 20` over OS processes, /root/reference/README.md:110-115)."""
+    port = a.master_port or _free_port()
+    args = [x for x in sys.argv[1:]]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, cwd=ROOT)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    if r.returncode == 0 and not lines:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no JSON line\n")
+        return 1
+    return r.returncode
 
 
 def chain_lengths(w, idx=None):
@@ -109,12 +151,24 @@ def chain_lengths(w, idx=None):
     return chains
 
 
+def follow_limit():
+    """Chains up to which a batch runs one chain per wave with the trunk wave following (misti_consts.h)."""
+    try:
+        txt = open(os.path.join(ROOT, "misti_amd", "csrc", "misti_consts.h")).read()
+        import re
+        m = re.search(r"FOLLOW_MAX_CHAINS\s*=\s*(\d+)", txt)
+        return int(m.group(1)) if m else 256
+    except Exception:
+        return 256
+
+
 def algorithmic_bytes(w, n_rep, idx=None):
     """HBM bytes the algorithm needs per launch, per kernel.
 
     correction: one chain per distinct parameter vector, computed up to the largest split index of
                 its members: 8P in; per interval 16 B of rates + 48 B of pair state out (+ the trunk records,
-                1 056 B per chain and interval, when the trunk wave follows its chain in the same launch);
+                1 056 B per chain and interval from the first interval a member reads, when the trunk wave follows
+                its chain in the same launch);
     spectrum:   per candidate split 8 + params 8P in, its share of the chain 16 B per two-population
                 interval + 48 B state, JAFS 56 + status 4 out (+ one trunk record of 1 056 B when chains are
                 shared; the trunk launch itself writes one record per chain and interval);
@@ -129,7 +183,7 @@ def algorithmic_bytes(w, n_rep, idx=None):
     if len(chains) * 8 <= n:                                  # TRUNK_MIN_SHARE (misti_consts.h): chains are shared, a trunk is built
         trunk = sum(1056 * (L + 1) for L in chains.values())
         spectrum += 1056 * n                                  # one trunk record per candidate
-        if len(chains) <= 256 or n <= 2048:                   # one chain per wave: the trunk wave follows its chain inside the chain launch
+        if len(chains) <= follow_limit():                     # one chain per wave: the trunk wave follows its chain inside the chain launch
             correct += trunk
         else:
             spectrum += trunk
@@ -157,24 +211,65 @@ def cpu_baseline_child(w, idx, cores, idx_compiled):
         return {k: d[k] for k in d.files}
 
 
+def dry_run(a, json_fd):
+    """Launcher rehearsal on CPU: gloo ranks shard ONE stub grid with misti_amd.dist.evaluate_sharded (the library's
+    multi-rank entry point) and gather it.  The stub evaluator is a closed-form function of (split, rate) - neither the
+    engine nor the oracle - so this checks process start, rendezvous, sharding, the gather and the one-line protocol."""
+    import torch.distributed as dist
+    from misti_amd.dist import env_rank, evaluate_sharded, shard_indices
+    rank, local_rank, world = env_rank()
+    if a.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+    n = 37                                                     # ragged on purpose
+    split = 20.0 + np.arange(n)
+    params = (0.01 * (1 + np.arange(n)))[:, None]
+    jsfs = np.ones((2, 8))
+    stub = lambda s, p, j: np.stack([-(s + p[:, 0]), -(2 * s + p[:, 0])], axis=1)
+    t0 = time.perf_counter()
+    for _ in range(max(1, a.steps)):
+        got = evaluate_sharded(stub, split, params, jsfs).numpy()
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(got, stub(split, params, jsfs)))
+    mine = shard_indices(n, rank, world)
+    if rank == 0:
+        out = {"metric": "dry-run (launcher rehearsal, no measurement)", "value": None, "unit": "llk evals/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": 1e3 * dt / max(1, a.steps), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
+               "dtype": "f64", "data": "dry-run",
+               "config": {"workload": "stub grid of %d candidates x 2 replicates" % n, "world_size": dist.get_world_size() if world > 1 else 1,
+                          "backend": "gloo", "candidates_rank0": int(len(mine))},
+               "gather_equals_unsharded": ok}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def build_workload(name, spec):
+    from misti_amd import workloads
+    return workloads.BUILDERS[name](spec)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(a)
     # stdout carries exactly one JSON line: libraries that print banners there (RCCL prints its version
     # block on communicator creation) are sent to stderr for the whole run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if a.dry_run:
+        return dry_run(a, json_fd)
     import torch
     import torch.distributed as dist
-    from misti_amd import workloads
     from misti_amd.dist import env_rank, shard_indices
     from misti_amd.engine import Engine, truth_spectrum
 
     rank, local_rank, world = env_rank()
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (a.gpus, world))
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -190,142 +285,175 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     group_world = dist.get_world_size() if use_dist else 1      # what the process group itself reports
 
-    # ---- workload ---------------------------------------------------------------
     spec = lambda *args: truth_spectrum(*args, device=local_rank)
-    if a.workload == "config3-search":
+    if a.workload in ("config3-search", "config3-basinhopping"):
         from misti_amd import search_bench
         return search_bench.run(a, spec, dev, local_rank, rank, world, json_fd)
-    w = workloads.BUILDERS[a.workload](spec)
-    strong = a.scaling == "strong"
-    if strong:
-        mine = shard_indices(w.n_cand, rank, world, interleave=True)      # ONE grid, interleaved shards
-    else:
-        mine = np.arange(w.n_cand)
-        if world > 1 and w.params is not None:
-            # distinct grids per rank (weak scaling): shift the rate axis by a rank-dependent factor
-            w.params = w.params * (1.0 + 0.01 * rank)
-    n_total = w.n_cand
-    n, R, P = len(mine), int(w.jsfs.shape[0]), w.n_param
-    per = -(-n_total // world) if strong else n                             # rows every rank contributes to the gather
-    d_split = torch.as_tensor(w.split_time[mine], dtype=torch.float64, device=dev)
-    d_par = torch.as_tensor(w.params[mine], dtype=torch.float64, device=dev).contiguous() if P else None
-    d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
-    bucket = max(1, a.gather_bucket) if use_dist else 1
-
-    torch.cuda.synchronize()                          # inputs have landed before any lane (non-blocking streams) reads them
-
-    class Lane:
-        """One engine context + its output buffers on one HIP stream.
-
-        A lane issues on its engine's OWN stream (hipStreamCreate inside misti_create): streams created
-        one by one map to distinct hardware queues, whereas streams handed out by torch's pool share
-        them (measured: ~11 long kernels in flight on 12 own streams against ~6 on 16 pool streams)."""
-        def __init__(self):
-            self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
-            self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
-            # multi-GPU: the llk of `bucket` consecutive batches of this lane are gathered by ONE collective (a 32 KB all_gather
-            # per batch is pure latency on xGMI and costs a fifth of the rate); every batch's llk still reaches every rank
-            self.slots = torch.full((bucket, per, R), float("nan"), dtype=torch.float64, device=dev)   # rows beyond n: padding of a ragged shard
-            self.gathered = torch.empty((world * bucket * per, R), dtype=torch.float64, device=dev) if use_dist else None
-            self.fill = 0
-            self.llk = self.slots[0]
-            self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
-            self.status = torch.empty(n, dtype=torch.int32, device=dev)
-
-        def step(self):
-            self.llk = self.slots[self.fill]
-            self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
-                                  self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
-            if use_dist:
-                self.fill += 1
-                if self.fill == bucket:
-                    self.flush()
-
-        def flush(self):
-            """The bucket's collective, issued from the lane's own stream: c10d orders it after the batches (event on this
-            stream), runs it on its communicator stream in host issue order - the same on every rank - and makes this
-            stream wait for it, so the next batch of the lane cannot overwrite a slot early.  (A dedicated communication
-            stream + events per step cost a hardware queue and 15 % of the rate.)  A partly filled bucket is gathered whole."""
-            if use_dist and self.fill > 0:
-                with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(self.gathered, self.slots.view(bucket * per, R))
-                self.fill = 0
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    host_issue = [0.0]
+    def leg(workload, scaling, steps, warmup, min_seconds, n_streams, serial_pass=True, keep=False):
+        """One measured leg: `steps` steps of `workload` round-robin on n_streams lanes (weak: every rank its own grid;
+        strong: ONE grid sharded over the ranks), W warmup steps first, the K-step region repeated until min_seconds."""
+        w = build_workload(workload, spec)
+        strong = scaling == "strong"
+        if strong:
+            mine = shard_indices(w.n_cand, rank, world, interleave=True)      # ONE grid, interleaved shards (SURVEY 8e)
+        else:
+            mine = np.arange(w.n_cand)
+            if world > 1 and w.params is not None:
+                # distinct grids per rank (weak scaling): shift the rate axis by a rank-dependent factor
+                w.params = w.params * (1.0 + 0.01 * rank)
+        n_total = w.n_cand
+        n, R, P = len(mine), int(w.jsfs.shape[0]), w.n_param
+        per = -(-n_total // world) if strong else n                             # rows every rank contributes to the gather
+        d_split = torch.as_tensor(w.split_time[mine], dtype=torch.float64, device=dev)
+        d_par = torch.as_tensor(w.params[mine], dtype=torch.float64, device=dev).contiguous() if P else None
+        d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
+        bucket = max(1, a.gather_bucket) if use_dist else 1
+        torch.cuda.synchronize()                          # inputs have landed before any lane (non-blocking streams) reads them
 
-    def timed(lanes, steps):
-        """EXACTLY `steps` steps issued round-robin on `lanes` between two fences; seconds (max over ranks)."""
-        fence()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            lanes[i % len(lanes)].step()
-        for lane in lanes:                           # what is still in a bucket belongs to the timed steps
-            lane.flush()
-        host_issue[0] = time.perf_counter() - t0
-        fence()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        class Lane:
+            """One engine context + its output buffers on one HIP stream.
 
-    def repeated(lanes, steps, warmup, min_seconds):
-        """W untimed warmup steps, then the K-step timed region again and again until the regions add up to
-        min_seconds (at least once, at most 200 times; every rank takes the same decision: dt is the all-reduced max)."""
-        for i in range(warmup):
-            lanes[i % len(lanes)].step()
+            A lane issues on its engine's OWN stream (hipStreamCreate inside misti_create): streams created
+            one by one map to distinct hardware queues, whereas streams handed out by torch's pool share
+            them (measured: ~11 long kernels in flight on 12 own streams against ~6 on 16 pool streams)."""
+            def __init__(self):
+                self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
+                self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
+                # multi-GPU: the llk of `bucket` consecutive batches of this lane are gathered by ONE collective (a 32 KB all_gather
+                # per batch is pure latency on xGMI and costs a fifth of the rate); every batch's llk still reaches every rank
+                self.slots = torch.full((bucket, per, R), float("nan"), dtype=torch.float64, device=dev)   # rows beyond n: padding of a ragged shard
+                self.gathered = torch.empty((world * bucket * per, R), dtype=torch.float64, device=dev) if use_dist else None
+                self.fill = 0
+                self.llk = self.slots[0]
+                self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
+                self.status = torch.empty(n, dtype=torch.int32, device=dev)
+
+            def step(self):
+                self.llk = self.slots[self.fill]
+                self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
+                                      self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
+                if use_dist:
+                    self.fill += 1
+                    if self.fill == bucket:
+                        self.flush()
+
+            def flush(self):
+                """The bucket's collective, issued from the lane's own stream: c10d orders it after the batches (event on this
+                stream), runs it on its communicator stream in host issue order - the same on every rank - and makes this
+                stream wait for it, so the next batch of the lane cannot overwrite a slot early.  (A dedicated communication
+                stream + events per step cost a hardware queue and 15 % of the rate.)  A partly filled bucket is gathered whole."""
+                if use_dist and self.fill > 0:
+                    with torch.cuda.stream(self.stream):
+                        dist.all_gather_into_tensor(self.gathered, self.slots.view(bucket * per, R))
+                    self.fill = 0
+
+            def close(self):
+                self.eng.sync()
+                self.stream = None
+                self.eng.close()
+
+        host_issue = [0.0]
+
+        def timed(lanes, k):
+            """EXACTLY `k` steps issued round-robin on `lanes` between two fences; seconds (max over ranks)."""
+            fence()
+            t0 = time.perf_counter()
+            for i in range(k):
+                lanes[i % len(lanes)].step()
+            for lane in lanes:                           # what is still in a bucket belongs to the timed steps
+                lane.flush()
+            host_issue[0] = time.perf_counter() - t0
+            fence()
+            dt = time.perf_counter() - t0
+            if use_dist:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt
+
+        def repeated(lanes, k, wu, min_s):
+            """W untimed warmup steps, then the K-step timed region again and again until the regions add up to
+            min_seconds (at least once, at most 200 times; every rank takes the same decision: dt is the all-reduced max)."""
+            for i in range(wu):
+                lanes[i % len(lanes)].step()
+            for lane in lanes:
+                lane.flush()
+            dts = []
+            while not dts or (sum(dts) < min_s and len(dts) < 200):
+                dts.append(timed(lanes, k))
+            return dts
+
+        lanes = [Lane() for i in range(max(1, n_streams))]
+        # context initialisation, not measurement: the first batch of a context allocates its workspaces (hipMalloc) and
+        # learns its launch shape; every lane does that once here so that a short run (K < lanes x a few) times steady state
         for lane in lanes:
-            lane.flush()
-        dts = []
-        while not dts or (sum(dts) < min_seconds and len(dts) < 200):
-            dts.append(timed(lanes, steps))
-        return dts
+            lane.step()
+        fence()
+        dts = repeated(lanes, steps, warmup, min_seconds)
+        dt = statistics.median(dts)
+        res = {"w": w, "mine": mine, "n": n, "n_total": n_total, "R": R, "P": P, "strong": strong, "bucket": bucket,
+               "dts": dts, "dt": dt, "issue": host_issue[0], "steps": steps, "n_streams": len(lanes)}
+        job_cands = n_total if strong else world * n          # candidates all ranks evaluate per step
+        res["job_cands"] = job_cands
+        res["value"] = job_cands * R * steps / dt
+        if serial_pass:
+            # strictly serial pass on one stream: the per-grid latency, and the per-kernel durations (HIP events on the launch stream)
+            serial = lanes[0]
+            eng = serial.eng
+            k_serial = max(4, min(steps, 16))
+            dts_serial = repeated([serial], k_serial, 2, min_seconds)
+            res["dt_serial"], res["k_serial"], res["repeats_serial"] = statistics.median(dts_serial), k_serial, len(dts_serial)
+            eng.enable_timing(True)
+            eng.kernel_times(reset=True)
+            timed([serial], k_serial)
+            res["kms"], res["kn"] = eng.kernel_times(reset=True)
+            eng.enable_timing(False)
+        res["status"] = lanes[0].status.cpu().numpy()
+        res["llk"] = lanes[0].llk[:n].cpu().numpy()
+        chains_mine = len(chain_lengths(w, mine))
+        if use_dist:
+            t = torch.zeros(world, dtype=torch.int64, device=dev)
+            t[rank] = chains_mine
+            dist.all_reduce(t)
+            res["chains_per_rank"] = [int(v) for v in t.cpu()]
+            cand_t = torch.zeros(world, dtype=torch.int64, device=dev)
+            cand_t[rank] = n
+            dist.all_reduce(cand_t)
+            res["cands_per_rank"] = [int(v) for v in cand_t.cpu()]
+        else:
+            res["chains_per_rank"], res["cands_per_rank"] = [chains_mine], [n]
+        if keep:
+            res["lanes"] = lanes
+        else:
+            for lane in lanes:
+                lane.close()
+        return res
+
+    def block(res, note=None):
+        """A secondary leg as a JSON block."""
+        b = {"workload": res["w"].name, "value": res["value"], "unit": "llk evals/s", "ms_per_step": 1e3 * res["dt"] / res["steps"], "steps": res["steps"],
+             "streams": res["n_streams"], "candidates_total": res["job_cands"], "replicates": res["R"], "repeats": len(res["dts"]),
+             "candidates_per_rank": res["cands_per_rank"], "chains_per_rank": res["chains_per_rank"],
+             "status_ok_fraction": float((res["status"] == 0).mean())}
+        if "dt_serial" in res:
+            b["single_batch_ms"] = 1e3 * res["dt_serial"] / res["k_serial"]
+            b["ms_per_launch"] = {k: (res["kms"][k] / res["kn"][k] if res["kn"][k] else 0.0) for k in res["kms"]}
+        if note:
+            b["note"] = note
+        return b
 
     n_streams = max(1, a.streams)
-    main_lanes = [Lane() for i in range(n_streams)]
-    # context initialisation, not measurement: the first batch of a context allocates its workspaces (hipMalloc) and
-    # learns its launch shape; every lane does that once here so that a short run (K < lanes x a few) times steady state
-    for lane in main_lanes:
-        lane.step()
-    fence()
-    dts = repeated(main_lanes, a.steps, a.warmup, a.min_seconds)
-    dt = statistics.median(dts)
-    issue_main = host_issue[0]
-    # strictly serial pass on one stream: the per-grid latency, and the per-kernel durations (HIP events on the launch stream)
-    serial = main_lanes[0]
-    eng = serial.eng
-    k_serial = max(4, min(a.steps, 16))
-    dts_serial = repeated([serial], k_serial, 2, a.min_seconds)
-    dt_serial = statistics.median(dts_serial)
-    eng.enable_timing(True)
-    eng.kernel_times(reset=True)
-    timed([serial], k_serial)
-    kms, kn = eng.kernel_times(reset=True)
-    eng.enable_timing(False)
-
-    status = serial.status.cpu().numpy()
-    llk = serial.llk[:n].cpu().numpy()
-    job_cands = n_total if strong else world * n          # candidates all ranks evaluate per step
-    evals = job_cands * R * a.steps
-    value = evals / dt
-    chains_mine = len(chain_lengths(w, mine))
-    if use_dist:
-        t = torch.zeros(world, dtype=torch.int64, device=dev)
-        t[rank] = chains_mine
-        dist.all_reduce(t)
-        chains_per_rank = [int(v) for v in t.cpu()]
-        cand_t = torch.zeros(world, dtype=torch.int64, device=dev)
-        cand_t[rank] = n
-        dist.all_reduce(cand_t)
-        cands_per_rank = [int(v) for v in cand_t.cpu()]
-    else:
-        chains_per_rank, cands_per_rank = [chains_mine], [n]
+    main_leg = leg(a.workload, a.scaling, a.steps, a.warmup, a.min_seconds, n_streams)
+    w, mine, n, R, dt, dts = main_leg["w"], main_leg["mine"], main_leg["n"], main_leg["R"], main_leg["dt"], main_leg["dts"]
+    strong, bucket, job_cands, value = main_leg["strong"], main_leg["bucket"], main_leg["job_cands"], main_leg["value"]
+    status, llk = main_leg["status"], main_leg["llk"]
+    kms, kn, dt_serial, k_serial = main_leg["kms"], main_leg["kn"], main_leg["dt_serial"], main_leg["k_serial"]
 
     metric = "composite-llk evals/sec over (split×mi) grid, 128 merged PSMC intervals"
     try:                                              # the exact string of BASELINE.json when it is at hand
@@ -339,7 +467,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": w.name, "candidates_per_gpu": n, "candidates_total": job_cands, "replicates": R, "numT": w.numT,
                    "batches_in_flight": n_streams, "streams": n_streams,
-                   "world_size": group_world, "candidates_per_rank": cands_per_rank, "chains_per_rank": chains_per_rank,
+                   "world_size": group_world, "candidates_per_rank": main_leg["cands_per_rank"], "chains_per_rank": main_leg["chains_per_rank"],
                    "gather_bucket": bucket if use_dist else None,
                    "parallelism": ("ONE grid sharded over the ranks (interleaved), all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket if strong else
                                    "every rank its own grid, all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket) if world > 1 else "1 GPU"},
@@ -348,9 +476,28 @@ def main():
                    "note": "value and ms_per_step are the MEDIAN repetition of the K-step timed region (each between barriers, max over ranks)"},
     }
     out_spectra_per_s = job_cands * a.steps / dt
+
+    # ---- secondary legs (every rank runs them: they contain collectives) -------------------------------------------------
+    extra = {}
+    if not a.no_extra_legs:
+        short = max(8, min(a.steps, 64))
+        if world > 1:
+            # both scalings in one line: the headline leg is one of them, the other one here
+            other = "strong" if a.scaling == "weak" else "weak"
+            o_leg = leg("config5" if other == "strong" else "config2", other, short, min(a.warmup, 16), a.min_seconds, n_streams, serial_pass=False)
+            extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, interleaved" if other == "strong"
+                                 else "every rank its own config-2 grid")
+            extra[a.scaling] = block(main_leg, "the headline leg above")
+        elif a.workload == "config2":
+            # ONE call on ONE stream at the overlapped rate: 16 config-2 grids with distinct rate axes in one batch
+            s_leg = leg("config2x16", "weak", max(4, min(a.steps, 32)), 4, a.min_seconds, 1, serial_pass=True)
+            extra["single_call"] = block(s_leg, "16 config-2 grids with distinct rate axes (65 536 candidates, 1 024 chains) as ONE misti_eval_batch_dev "
+                                                "call per step, strictly one after another on ONE stream")
+
     if rank == 0:
+        out.update(extra)
         out["single_batch"] = {"value": job_cands * R * k_serial / dt_serial, "ms_per_step": 1e3 * dt_serial / k_serial, "steps": k_serial,
-                               "streams": 1, "repeats": len(dts_serial),
+                               "streams": 1, "repeats": main_leg["repeats_serial"],
                                "note": "the same step issued strictly one after another on one stream: one grid's latency, bounded by its "
                                        "longest lambda-correction chain (up to ~900 dependent residual evaluations in the runaway corner of "
                                        "the grid); `value` above overlaps config.batches_in_flight such batches"}
@@ -360,23 +507,7 @@ def main():
         dom = max(("correct", "spectrum"), key=lambda k: per_ms[k])
         ab = algorithmic_bytes(w, R, mine)
         achieved = ab[dom] / (per_ms[dom] * 1e-3) / 1e9 if per_ms[dom] > 0 else 0.0
-        traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc) and world == 1:
-            try:
-                j = json.load(open(pmc))
-                if j.get("workload") == a.workload:
-                    traffic = j.get(dom + "_hbm_bytes_per_launch")
-                    traffic_source = "stored: profiles/pmc_latest.json <- " + str(j.get("source")) + " (not measured in this run)"
-            except Exception:
-                traffic = None
-        out["roofline"] = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                           "algorithmic_bytes_per_launch": ab[dom], "candidates_per_launch": n, "chains_per_launch": ab["n_chains"],
-                           "ms_per_launch": per_ms,
-                           "note": "the path is neither HBM- nor MFMA-bound (SURVEY 8d): ~1 KB per candidate against ~1e5 dependent fp64 "
-                                   "operations; the correction kernel is bound by the dependent-issue latency of its longest chain "
-                                   "(serial trust-region iterations of the reference's solver), the spectrum kernel by fp64 VALU issue + LDS latency"}
+        out["roofline"] = roofline_block(a.workload, world, dom, per_ms, ab, achieved, n)
         # secondary figure SURVEY 8d asks for: the flop model of an UNSHARED evaluation (what the reference computes per
         # candidate: ~16 sparse generator applications of 2 x 220 flop per two-population interval, ~5 kflop of 3x3
         # exponentials per migrating interval, 0.1 kflop per one-population interval) x distinct spectra per second,
@@ -391,7 +522,7 @@ def main():
         out["status_fraction"] = {"ok": float(ok.mean()), "correction_failed": float((status == 2).mean()),
                                   "stiff": float((status == 6).mean()), "numeric": float((status == 5).mean())}
         out["spectrum_evals_per_s"] = out_spectra_per_s
-        out["host_issue_ms_per_step"] = 1e3 * issue_main / a.steps
+        out["host_issue_ms_per_step"] = 1e3 * main_leg["issue"] / a.steps
         # ---- CPU baseline: the oracle on this box's host cores, bounded sample, in a child process ----------
         if world == 1 and not a.no_cpu_baseline:
             cores = min(os.cpu_count() or 1, 16)
@@ -436,7 +567,48 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
+    """`roofline` of the dominant kernel.  HBM: algorithmic bytes / HIP-event duration (measured in this run) against 8 TB/s, with the
+    counter traffic of the same kernel from profiles/pmc_latest.json (rocprofv3 --pmc passes of the same command; stored, keyed
+    by workload).  VALU: what actually binds - wave-instructions issued against the chip's issue slots."""
+    traffic, traffic_source, valu = None, None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc) and world == 1:
+        try:
+            j = json.load(open(pmc))
+            j = j.get("workloads", {}).get(workload) or (j if j.get("workload") == workload else None)
+            if j:
+                traffic = j.get(dom + "_hbm_bytes_per_launch")
+                traffic_source = "stored: profiles/pmc_latest.json <- " + str(j.get("source")) + " (not measured in this run)"
+                v = j.get(dom + "_valu")
+                if v and per_ms[dom] > 0:
+                    # 4 SIMDs x 256 CUs; a wave-instruction in fp64 occupies its SIMD's VALU for 4 cycles (16 lanes per cycle)
+                    cycles = per_ms[dom] * 1e-3 * GPU_CLOCK_HZ
+                    valu = {"wave_insts": v.get("SQ_INSTS_VALU"), "lane_occupancy": v.get("lane_occupancy"),
+                            "frac": 4.0 * v["SQ_INSTS_VALU"] / (N_SIMD * cycles) if v.get("SQ_INSTS_VALU") else None,
+                            "kernel_cycles": cycles, "clock_hz": GPU_CLOCK_HZ, "simds": N_SIMD,
+                            "waves_launched": v.get("SQ_WAVES"), "busy_cycles": v.get("SQ_BUSY_CYCLES"),
+                            "source": "SQ counters stored in profiles/pmc_latest.json (rocprofv3 --pmc pass of this command), duration measured in this run",
+                            "note": "frac = 4 x SQ_INSTS_VALU / (1 024 SIMDs x kernel cycles): share of the chip's fp64 VALU issue slots this launch used"}
+        except Exception:
+            traffic = None
+    bound = "hbm"
+    blk = {"bound": bound, "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+           "algorithmic_bytes_per_launch": ab[dom], "candidates_per_launch": n, "chains_per_launch": ab["n_chains"],
+           "ms_per_launch": per_ms,
+           "binding_resource": "dependent fp64 VALU issue of the longest lambda-correction chain (latency), not HBM and not MFMA",
+           "note": "the contract's two bounds are hbm | mfma; neither binds this path (SURVEY 8d): ~1 KB per candidate against ~1e5 dependent fp64 "
+                   "operations.  The hbm fraction is reported as asked; `valu` is the resource that binds: the correction kernel by the "
+                   "dependent-issue latency of its longest chain (serial trust-region iterations of the reference's solver), the spectrum "
+                   "kernel by fp64 VALU issue + LDS latency"}
+    if valu:
+        blk["valu"] = valu
+    return blk
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

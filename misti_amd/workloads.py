@@ -85,6 +85,18 @@ def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, t
     return w
 
 
+def config2x16(spectrum_fn, n_grid=16, **kw):
+    """``n_grid`` config-2 grids with distinct rate axes in ONE batch (the README's ``st x mc x rates`` sweep as a caller
+    with one large sweep issues it, /root/reference/README.md:113): grid g scales the rate axis by 1 + g/64, so every
+    (grid, rate) pair is its own chain - 65 536 candidates in 1 024 chains for the default 16 x (64 x 64)."""
+    w = config2(spectrum_fn, **kw)
+    split = np.tile(w.split_time, n_grid)
+    par = np.concatenate([w.params * (1.0 + g / 64.0) for g in range(n_grid)], axis=0)
+    w.name = "config2x%d: %d config-2 grids with distinct rate axes in one batch (%d candidates), --cpfit" % (n_grid, n_grid, split.shape[0])
+    w.split_time, w.params = split, par
+    return w
+
+
 def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6):
     """Two optimised bands, random starts (one batched simplex-vertex evaluation)."""
     inp = synth.psmc_pair(64, 65)
@@ -139,4 +151,4 @@ def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true
     return w
 
 
-BUILDERS = {"config1": config1, "config2": config2, "config3": config3, "config4": config4, "config5": config5}
+BUILDERS = {"config1": config1, "config2": config2, "config2x16": config2x16, "config3": config3, "config4": config4, "config5": config5}
