@@ -76,6 +76,7 @@ struct misti_ctx {
     int32_t* hint_host = nullptr;       // pinned, device-visible: {chains, candidates} of the last batch (a launch-shape hint only)
     int32_t* hint_dev = nullptr;
     int32_t batch_seq = 0;
+    misti::Tuning tune;                 // diagnostic launch-shape overrides, read from the environment once (misti_create)
     int table_cur = 0;                  // which of the two chain-table sets the next batch uses
     size_t table_clean[2] = {0, 0};     // table size each set is known to be clean for (0: not clean)
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
@@ -226,11 +227,11 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const size_t nc = (size_t)n_cand, numT = (size_t)c->dm.numT;
     // chain machinery: one allocation per type, carved below
     const size_t tsize = misti::chain_table_size(n_cand);
-    const size_t ntr = (size_t)misti::trunk_capacity(n_cand);
+    const size_t ntr = (size_t)misti::trunk_capacity(n_cand, c->tune);
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
     // chain tables: TWO sets {n_chains[2], table, slot_chain, slot_len} used alternately - a batch clears the other set for its successor
-    const size_t set_n = 2 + 3 * tsize;
-    const size_t i32_n = 2 * set_n + 7 * nc + ntr;          // two table sets | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status | trunk_ok
+    const size_t set_n = 4 + 4 * tsize;                     // counters [4] | table | slot_chain | slot_len | slot_keep
+    const size_t i32_n = 2 * set_n + 8 * nc + ntr;          // two table sets | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status, chain_order | trunk_ok
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
     {
         void* before = c->ws_chain_i32.p;
@@ -256,10 +257,11 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         if (c->table_clean[cur] != tsize) HIP_TRY(hipMemsetAsync(set[cur], 0, set_n * sizeof(int32_t), c->stream));
         c->table_clean[cur] = 0;                    // about to be used
         c->table_clean[cur ^ 1] = 0;                // until the setup launch below is in the stream
-        cb.n_chains = set[cur]; cb.table = set[cur] + 2; cb.slot_chain = cb.table + tsize; cb.slot_len = cb.slot_chain + tsize;
-        cb.z_n_chains = set[cur ^ 1]; cb.z_table = set[cur ^ 1] + 2; cb.z_slot_len = cb.z_table + 2 * tsize;
+        cb.n_chains = set[cur]; cb.table = set[cur] + 4; cb.slot_chain = cb.table + tsize; cb.slot_len = cb.slot_chain + tsize;
+        cb.slot_keep = cb.slot_len + tsize;
+        cb.z_n_chains = set[cur ^ 1]; cb.z_table = set[cur ^ 1] + 4; cb.z_slot_len = cb.z_table + 2 * tsize; cb.z_slot_keep = cb.z_slot_len + tsize;
         cb.slot_of = q; q += nc; cb.of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
-        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc;
+        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc; cb.chain_order = q; q += nc;
         cb.trunk_ok = q;
         cb.tmask = (uint32_t)(tsize - 1);
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
@@ -309,12 +311,11 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // counts when batches overlap - unless it is known to collapse into a few long chains (pure latency: one chain
     // per wave and the trunk following it)
     auto shape = [&](int64_t est, int& cpw, bool& follow) {
-        cpw = (est >= 0 && est <= 256) ? 1 : misti::correct_cands_per_wave(n_cand);
-        if (const char* e = getenv("MISTI_CHAINS_PER_WAVE")) {     // diagnostic override (scratch experiments), read per call
-            const int f = atoi(e);
-            if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10) cpw = f;
-        }
-        follow = misti::trunk_follows(cpw, (int64_t)ntr);
+        const int64_t follow_max = c->tune.follow_max > 0 ? c->tune.follow_max : misti::FOLLOW_MAX_CHAINS;
+        cpw = (est >= 0 && est <= follow_max) ? 1 : misti::correct_cands_per_wave(n_cand, c->tune);
+        const int f = c->tune.chains_per_wave;                       // diagnostic override (scratch experiments, tests)
+        if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10) cpw = f;
+        follow = misti::trunk_follows(cpw, (int64_t)ntr, c->tune);
     };
     // a batch is four launches (+1 for the default fit, +1 with more than LLK_INLINE_MAX replicates): setup | chains |
     // trunks + tails | candidates (+ replicate epilogue).  Few launches matter when many batches are in flight.
@@ -323,11 +324,10 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const bool llk_inline = n_rep > 0 && n_rep <= misti::LLK_INLINE_MAX;
     hipEvent_t a = nullptr, b = nullptr;
     if (int r = record_begin(c, 0, &a, &b)) return r;
-    HIP_TRY_EV(misti::launch_setup(n_cand, c->dm.n_param, cb.bounds ? c->dm.n_band : 0, d_params, d_split, c->dm.numT, cb, d_order,
-                                   n_rep, d_jsfs, d_consts, c->unfolded, c->stream), a, b);
+    HIP_TRY_EV(misti::launch_setup(c->dm, n_cand, d_params, d_split, cb, d_order, n_rep, d_jsfs, d_consts, c->unfolded, c->stream), a, b);
     c->table_clean[c->table_cur ^ 1] = tsize;       // setup_kernel clears the other set (table, slot_len, counters) for this table size
     c->table_cur ^= 1;
-    if (est_chains < 0 && hint && misti::correct_cands_per_wave(n_cand) > 1) {
+    if (est_chains < 0 && hint && misti::correct_cands_per_wave(n_cand, c->tune) > 1) {
         const auto t0 = std::chrono::steady_clock::now();
         while (hint[2] != cb.seq && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(500)) std::this_thread::yield();
         if (hint[2] == cb.seq && hint[1] == (int32_t)n_cand) est_chains = hint[0];
@@ -335,14 +335,14 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     int cpw_chains = 1;
     bool follow = false;
     shape(est_chains, cpw_chains, follow);
-    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->stream), a, b);
+    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, c->stream), a, b);
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
     if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                      n_rep, d_jsfs, d_consts, d_llk, follow, c->stream), a, b);
+                                      n_rep, d_jsfs, d_consts, d_llk, follow, c->tune, c->stream), a, b);
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {
@@ -395,6 +395,7 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
     struct Guard { misti_ctx*& c; bool keep = false; ~Guard() { if (!keep && c) { misti_destroy(c); c = nullptr; } } } guard{c};
     try {
         c = new misti_ctx();
+        c->tune = misti::read_tuning();
         const misti::HostTables& t = host_tables();
         c->device = device;
         HIP_TRY(hipSetDevice(device));

@@ -15,5 +15,11 @@ constexpr int INV_TABLE = 1024;         // reciprocal table for the series (also
 constexpr int TRUNK_REC = 3 * NS2;    // doubles per trunk record: state vector | occupation integral before | from the sample date
 constexpr int TRUNK_MAX_CHAINS = 8192; // trunk buffer bound: 8 192 chains x numT records x 1 056 B (1.1 GB at numT = 128)
 constexpr int TRUNK_MIN_SHARE = 8;    // the trunk runs when a chain has on average at least this many candidates
+constexpr int FOLLOW_MAX_CHAINS = 1024; // up to this many chains a batch runs one chain per wave (speculation, trunk wave following), workgroups
+                                        // pulling chains longest-first from a queue; beyond it chains are packed 10 per wave.  1 024 two-wave
+                                        // workgroups are resident at 2 waves per SIMD: one round.  Measured (MI355X): 1 024 chains 1.68 ms
+                                        // against 2.71 ms packed; 2 048 chains (config 5) 5.07 against 5.50 ms alone, and with 20 batches in
+                                        // flight 1.7e7 against 4.1e7 evals/s - a packed wave carries ten chains per instruction stream
+constexpr int FOLLOW_MIN_BLOCKS = 256;   // workgroups of the one-chain-per-wave launch whatever the (possibly stale) chain-count hint says
 constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
 }  // namespace misti

@@ -47,13 +47,17 @@ struct DevModel {
 // parameter vectors share a chain; chains are found by inserting every candidate into an open-addressing
 // table keyed by its parameters (discover_kernel): the first one in a slot owns the chain.
 struct ChainBufs {
-    int32_t* n_chains;      // [2]: chains; candidate blocks of setup_kernel that have finished
-    int32_t* z_n_chains;    // the OTHER set of {n_chains, table, slot_len}: cleared by this batch for the next one
+    int32_t* n_chains;      // [4]: chains; candidate blocks of setup_kernel that have finished; head of the chain queue; spare
+    int32_t* z_n_chains;    // the OTHER set of {n_chains, table, slot_len, slot_keep}: cleared by this batch for the next one
     int32_t* z_table;
     int32_t* z_slot_len;
+    int32_t* z_slot_keep;
     int32_t* table;         // [tsize] slot -> owner candidate + 1, 0 = empty
     int32_t* slot_chain;    // [tsize] slot -> chain
     int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
+    int32_t* slot_keep;     // [tsize] slot -> numT - (first interval at which a member leaves the trunk), max over members: the trunk
+                            //         stores its records from interval numT - slot_keep on (0: no member reads any)
+    int32_t* chain_order;   // [n] chains by descending length (the last candidate block of setup_kernel sorts them): dispatch order
     int32_t* slot_of;       // [n] candidate -> slot
     int32_t* of;            // [n] candidate -> chain, resolved by the idle blocks of the chain launch
     int32_t* chain_slot;    // [n] chain -> slot
@@ -134,17 +138,27 @@ constexpr int LLK_INLINE_MAX = 8;
 
 hipError_t upload_tables(const DevTables& t);
 size_t spectrum_lds_bytes(int numT);
-int64_t trunk_capacity(int64_t n_cand);
+// Diagnostic overrides of the launch shape, read from the environment ONCE per context (misti_create) - never on the batch path.
+struct Tuning {
+    int chains_per_wave = 0;   // MISTI_CHAINS_PER_WAVE: 1 | 2 | 4 | 8 | 10 forces the packing of the chain launch
+    int cands_per_wave = 0;    // MISTI_CANDS_PER_WAVE: ... of the packed kernels (chains and tails)
+    bool no_follow = false;    // MISTI_NO_FOLLOW=1: trunks in the launch after the chains
+    bool no_trunk = false;     // MISTI_NO_TRUNK=1: every candidate walks all its intervals
+    int follow_max = 0;        // MISTI_FOLLOW_MAX_CHAINS: chains up to which a batch runs one chain per wave (0: FOLLOW_MAX_CHAINS)
+    int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
+};
+Tuning read_tuning();
+int64_t trunk_capacity(int64_t n_cand, const Tuning& tn);
 uint32_t chain_table_size(int64_t n_cand);
-hipError_t launch_setup(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, int32_t* order,
+hipError_t launch_setup(const DevModel& m, int64_t n, const double* params, const double* split, const ChainBufs& cb, int32_t* order,
                         int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream);
-int correct_cands_per_wave(int64_t n_items);
-bool trunk_follows(int cpw_chains, int64_t trunk_cap);
+int correct_cands_per_wave(int64_t n_items, const Tuning& tn);
+bool trunk_follows(int cpw_chains, int64_t trunk_cap, const Tuning& tn);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, hipStream_t stream);
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream);
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, const Tuning& tn, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream);

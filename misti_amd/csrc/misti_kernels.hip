@@ -87,15 +87,16 @@ __device__ __forceinline__ double gbcast(double v, int j) {
 // Hand-over words in LDS between the two waves of a workgroup (correct_follow_kernel).  The pointers reach the
 // device functions as generic pointers and a volatile access through a generic pointer is a FLAT instruction with
 // system-scope cache bits followed by a wait for every outstanding global store; through an LDS-typed pointer it is a
-// plain ds_read / ds_write.  LDS serves one wave's accesses in issue order, so "data, then count" needs no more than
-// the compiler keeping that order (and lgkmcnt for the reader's data dependence).
+// plain ds_read / ds_write.  Ordering between the two waves ("data, then count" on the writer's side, "count, then data" on the
+// reader's) is a workgroup-scope release / acquire fence restricted to the LDS address space: it compiles to s_waitcnt lgkmcnt(0)
+// - no wait for the outstanding global stores of the chain - and is what the AMDGPU memory model asks for between waves (a
+// wavefront-scope fence orders nothing across waves and merely happened to work; the build never uses -mtgsplit).
 typedef __attribute__((address_space(3))) int lds_i32_t;
 __device__ __forceinline__ void lds_put(volatile int* p, int v) { *(volatile lds_i32_t*)(lds_i32_t*)p = v; }
 __device__ __forceinline__ int lds_get(const volatile int* p) { return *(const volatile lds_i32_t*)(lds_i32_t*)p; }
 __device__ __forceinline__ void lds_order() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the LDS writes before are done; no wait for global stores
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // A branch condition that is the same in every lane - everything of a chain is, when the chain has the wave to itself
@@ -1018,6 +1019,22 @@ __device__ __forceinline__ int setup_candidate(const DevModel& m, double st, con
     return status;
 }
 
+// First interval whose rates depend on THIS candidate's split - where it leaves the trunk of its chain: the start of the
+// smoothing run (of either genome) that the split cuts, or the shortened interval of a fractional split.  Used by the candidate
+// kernel (where to start from) and by setup_kernel (from which interval on the chain's trunk has to store records).
+__device__ __forceinline__ int trunk_leave(const DevModel& m, const Grid& G) {
+    int t_own = (G.ins >= 0) ? G.ins : G.split;
+    if (m.flags & MISTI_SMOOTH) {
+        if (G.ins >= 0) {
+            t_own = min(m.run_start[G.ins], m.run_start[m.numT + G.ins]);
+        } else if (G.split > 0) {
+            for (int k = 0; k < 2; ++k)
+                if (m.run_end[k * m.numT + G.split - 1] > G.split) t_own = min(t_own, m.run_start[k * m.numT + G.split - 1]);
+        }
+    }
+    return t_own;
+}
+
 // ------------------------------------------------------------ forward map ----
 // MigrationInference.CoalescentRates (MigrationInference.py:542-564) with CorrectLambda.CoalRates
 // (CorrectLambda.py:112-122): the model's own rates lh are taken as the TRUE per-population rates;
@@ -1099,21 +1116,25 @@ void forward_kernel(DevModel m, int64_t n_cand, const double* __restrict__ split
 template <bool CPFIT, int GROUP, bool TAIL, bool PRE = false>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
-                  int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr) {
+                  int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr,
+                  const int32_t* chain_map = nullptr) {
     const int lane = lane_id();
     const int sub = lane % GROUP;
     const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
     // GROUP = 6 packs ten items into a wave; its last four lanes belong to no item
-    const int64_t slot = (lane / GROUP < 64 / GROUP) ? (block * (64 / GROUP)) + (lane / GROUP) : n_live;
+    const int64_t pos = (lane / GROUP < 64 / GROUP) ? (block * (64 / GROUP)) + (lane / GROUP) : n_live;
     if (TAIL) {
         // a wave none of whose items has a fractional split has nothing to do: leave before staging
         bool mine = false;
-        if (slot < n_live) { const double st = split_time[slot]; mine = st != floor(st); }
+        if (pos < n_live) { const double st = split_time[pos]; mine = st != floor(st); }
         if (!__any(mine)) {
-            if (slot < n_live && sub == 0) cb.tail_status[slot] = MISTI_OK;
+            if (pos < n_live && sub == 0) cb.tail_status[pos] = MISTI_OK;
             return;
         }
     } else if (block * (64 / GROUP) >= n_live) return;
+    // chains of a packed launch (chain_map): position -> chain by descending length, so that the longest start first and the
+    // chains sharing a wave are of similar length; a chain's bits do not depend on where it runs
+    const int64_t slot = (!TAIL && chain_map && pos < n_live) ? (int64_t)chain_map[pos] : pos;
     // the shared grid (interval lengths, PSMC rates) staged in LDS: every pass of the state
     // machine of some item reads it, and an L2 round trip per read dominated the kernel
     {
@@ -1122,8 +1143,8 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         for (int i = lane; i < nl; i += 64) lds[nt + i] = m.lh[i];
     }
     lds_fence();                                   // staged and read by this wavefront only
-    if (slot >= n_live) return;
-    const int64_t cand = TAIL ? slot : (int64_t)cb.rep[slot];      // whose parameters
+    if (pos >= n_live) return;
+    const int64_t cand = TAIL ? slot : (int64_t)cb.rep[slot];      // whose parameters (chains: slot IS the chain id, see correct_kernel)
     const double* par = params ? params + cand * m.n_param : nullptr;
     Grid G;
     int status;
@@ -1552,7 +1573,7 @@ void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __r
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
     }
-    correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds);
+    correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, nullptr, nullptr, nullptr, cb.chain_order);
 }
 
 // ---- replicate epilogue pieces ----
@@ -1793,14 +1814,25 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     double x = (lane == 2) ? 1.0 : 0.0;
     double w_pre = 0.0, w_post = 0.0;
     double* rec = cb.trunk + ch * (int64_t)m.numT * TRUNK_REC;
+    // records are read from the first interval at which a member leaves the trunk (setup_kernel: slot_keep) - and at the
+    // interval the trunk ends on, wherever that is: a third of the records of a split x rate grid is never read
+    const int t_first = m.numT - cb.slot_keep[cb.chain_slot[ch]];
+    auto store = [&](int t, double xs, double ws0, double ws1) {
+        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = xs; r[NS2 + lane] = ws0; r[2 * NS2 + lane] = ws1; }
+    };
     int ok = 0;
+    bool stored = false;
+    double xs = x, ws0 = w_pre, ws1 = w_post;
     for (int t = 0; t < m.numT; ++t) {
-        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = x; r[NS2 + lane] = w_pre; r[2 * NS2 + lane] = w_post; }
+        xs = x; ws0 = w_pre; ws1 = w_post;
+        stored = t >= t_first;
+        if (stored) store(t, xs, ws0, ws1);
         ok = t;
         if (t >= Lt) break;
         if (t == m.sample_date) ancient_project(xbuf, lane, x);
         if (twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post) != MISTI_OK) break;
     }
+    if (!stored) store(ok, xs, ws0, ws1);
     if (lane == 0) cb.trunk_ok[ch] = ok;
 }
 
@@ -1833,10 +1865,18 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
     double w_pre = 0.0, w_post = 0.0;
     double* rec = cb.trunk + ch * (int64_t)m.numT * TRUNK_REC;
     const bool smooth = m.flags & MISTI_SMOOTH;
+    const int t_first = m.numT - cb.slot_keep[cb.chain_slot[ch]];         // see trunk_body
+    auto store = [&](int t, double xs, double ws0, double ws1) {
+        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = xs; r[NS2 + lane] = ws0; r[2 * NS2 + lane] = ws1; }
+    };
     int ok = 0, have = 0, done = 0;
+    bool stored = false;
+    double xs = x, ws0 = w_pre, ws1 = w_post;
     long long spins = 0;
     for (int t = 0; t < m.numT; ++t) {
-        if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = x; r[NS2 + lane] = w_pre; r[2 * NS2 + lane] = w_post; }
+        xs = x; ws0 = w_pre; ws1 = w_post;
+        stored = t >= t_first;
+        if (stored) store(t, xs, ws0, ws1);
         ok = t;
         if (t >= len) break;
         int a0 = t, b0 = t + 1, a1 = t, b1 = t + 1;
@@ -1863,6 +1903,7 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
         if (t == m.sample_date) ancient_project(xbuf, lane, x);
         if (twopop_interval(R, m, mod, G, lcb, xbuf, lane, t, x, w_pre, w_post) != MISTI_OK) break;
     }
+    if (!stored) store(ok, xs, ws0, ws1);
     if (lane == 0) cb.trunk_ok[ch] = ok;
 }
 
@@ -1883,16 +1924,22 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     extern __shared__ double lds[];
     double* tk = lds + 3 * (size_t)m.numT;
     double* lc_sh = tk + 128 + 2 * (size_t)(m.numT + 1);
-    volatile int* flags = (volatile int*)(lc_sh + 2 * (size_t)m.numT);
+    volatile int* flags = (volatile int*)(lc_sh + 2 * (size_t)m.numT);          // count, done | queue position of the chain in progress
     double* pre = lc_sh + 2 * (size_t)m.numT + 2;                              // per-interval constants of the chain in progress
     // candidate -> chain (see correct_kernel)
     for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 128) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
-    // The grid is sized from the chain count of the previous batch of this size (a hint the host has without waiting);
-    // a workgroup walks chains blockIdx.x, blockIdx.x + gridDim.x, ... so that any grid size is correct.
+    // Workgroups PULL chains from a queue, the longest first (cb.chain_order, sorted by setup_kernel; head = n_chains[2]): any
+    // grid is correct, and with more chains than resident workgroups (1 024 two-wave workgroups at two waves per SIMD) a
+    // workgroup that finishes a short chain takes the next one instead of waiting for a fixed stride partner.
     const int64_t n_live = cb.n_chains[0];
-    for (int64_t ch = blockIdx.x; ch < n_live; ch += gridDim.x) {
-        if (threadIdx.x == 0) { lds_put(flags, 0); lds_put(flags + 1, 0); }
+    if ((int64_t)blockIdx.x >= n_live) return;                                // more workgroups than chains (a generous grid): leave at once
+    int* next = (int*)(flags + 2);
+    for (;;) {
+        if (threadIdx.x == 0) { lds_put(flags, 0); lds_put(flags + 1, 0); *next = atomicAdd(&cb.n_chains[2], 1); }
         __syncthreads();
+        const int64_t pos = *next;
+        if (pos >= n_live) break;
+        const int64_t ch = cb.chain_order[pos];
         if (threadIdx.x < 64) {
             correct_body<CPFIT, 64, false, true>(m, n_items, cb, split_time, params, ch, lds, lc_sh, flags, pre);
             lds_order();
@@ -2057,17 +2104,9 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     const bool use_trunk = trunk_active(cb, n_cand);
     int smooth_from = 0;
     if (use_trunk) {
-        // first interval whose rates depend on this candidate's split: the start of the smoothing
-        // run (of either genome) that the split cuts; the shortened interval of a fractional split
-        int t_own = nfull;
-        if (m.flags & MISTI_SMOOTH) {
-            if (G.ins >= 0) {
-                t_own = min(m.run_start[G.ins], m.run_start[m.numT + G.ins]);
-            } else if (G.split > 0) {
-                for (int k = 0; k < 2; ++k)
-                    if (m.run_end[k * m.numT + G.split - 1] > G.split) t_own = min(t_own, m.run_start[k * m.numT + G.split - 1]);
-            }
-        }
+        // first interval whose rates depend on this candidate's split (trunk_leave); the trunk stores records from the
+        // smallest such interval of the chain's members on, and its last one where it ended early
+        const int t_own = trunk_leave(m, G);
         t0 = min(t_own, cb.trunk_ok[ch]);
         // smoothed rates below t0 are only needed for the optional lc output: skip them otherwise (a run that
         // reaches back below t_own still reads the unsmoothed values there: smoothing writes after all reads)
@@ -2258,15 +2297,16 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 //                             blocks out in index order, so the longest start first.  The order never affects a result;
 //   the blocks after it       llh_const of every replicate.
 __global__ __launch_bounds__(256)
-void setup_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, const double* __restrict__ split_time, int numT, ChainBufs cb,
+void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, const double* __restrict__ split_time, ChainBufs cb,
                   int cand_blocks, int32_t* __restrict__ order, int64_t n_rep, const double* __restrict__ jsfs, double* __restrict__ consts, int unfolded) {
+    const int numT = m.numT, P = m.n_param, NB2 = cb.bounds ? 2 * m.n_band : 0;
     if ((int)blockIdx.x > cand_blocks) {
         const int64_t r = (int64_t)((int)blockIdx.x - cand_blocks - 1) * blockDim.x + threadIdx.x;
         if (r < n_rep) consts[r] = llh_const_of(jsfs + r * 8, unfolded);
         return;
     }
+    __shared__ int hist[MISTI_MAX_NUMT + 4];
     if ((int)blockIdx.x == cand_blocks) {
-        __shared__ int hist[MISTI_MAX_NUMT + 4];
         const int nb = numT + 3;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
         __syncthreads();
@@ -2281,8 +2321,8 @@ void setup_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     {   // clear the other table for the next batch
         const int64_t tsize = (int64_t)cb.tmask + 1, nthr = (int64_t)cand_blocks * blockDim.x;
-        for (int64_t k = i; k < tsize; k += nthr) { cb.z_table[k] = 0; cb.z_slot_len[k] = 0; }
-        if (i == 0) { cb.z_n_chains[0] = 0; cb.z_n_chains[1] = 0; }
+        for (int64_t k = i; k < tsize; k += nthr) { cb.z_table[k] = 0; cb.z_slot_len[k] = 0; cb.z_slot_keep[k] = 0; }
+        if (i == 0) { cb.z_n_chains[0] = 0; cb.z_n_chains[1] = 0; cb.z_n_chains[2] = 0; cb.z_n_chains[3] = 0; }
     }
     if (i < n) {
         // the key: the parameter bits and, with per-candidate band bounds, the (start, end) pairs as given (end == -1
@@ -2314,20 +2354,45 @@ void setup_kernel(int64_t n, int P, int NB2, const double* __restrict__ params, 
         int need = 0;
         if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
         atomicMax(&cb.slot_len[sl], need);
-    }
-    // the last candidate block to finish tells the host how many chains there are: pinned memory, {chains, candidates, batch tag};
-    // the host uses it for the launch shape of kernel 1 (this batch if it cares to wait a few microseconds, else the next)
-    if (cb.hint) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(&cb.n_chains[1], 1) == cand_blocks - 1) {
-                cb.hint[0] = atomicAdd(cb.n_chains, 0);
-                cb.hint[1] = (int32_t)n;
-                __threadfence_system();
-                cb.hint[2] = cb.seq;
-            }
+        // from which interval on this candidate reads its chain's trunk (candidates without a value read nothing)
+        Grid G;
+        if (setup_candidate(m, st, P ? a : nullptr, G, ab) == MISTI_OK) {
+            int t_own = trunk_leave(m, G);
+            t_own = t_own < 0 ? 0 : (t_own > numT - 1 ? numT - 1 : t_own);
+            atomicMax(&cb.slot_keep[sl], numT - t_own);
         }
+    }
+    // The last candidate block to finish (a) sorts the chains by descending length - the dispatch order of the chain launch:
+    // workgroups pull chains from a queue, the longest first - and (b) tells the host how many chains there are: pinned memory,
+    // {chains, candidates, batch tag}; the host uses it for the launch shape of kernel 1 (this batch if it cares to wait a few
+    // microseconds, else the next).  Lengths and owners were written by other blocks: read at device scope.
+    __shared__ int is_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(&cb.n_chains[1], 1) == cand_blocks - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int nch = __hip_atomic_load(cb.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto len_of = [&](int ch) {
+        const int sl = __hip_atomic_load(&cb.chain_slot[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int L = __hip_atomic_load(&cb.slot_len[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return numT - (L < 0 ? 0 : (L > numT ? numT : L));                                   // key 0 = the longest
+    };
+    for (int k = threadIdx.x; k < numT + 2; k += blockDim.x) hist[k] = 0;
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < nch; ch += blockDim.x) atomicAdd(&hist[len_of(ch)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < numT + 2; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < nch; ch += blockDim.x) { const int pos = atomicAdd(&hist[len_of(ch)], 1); cb.chain_order[pos] = ch; }
+    if (cb.hint && threadIdx.x == 0) {
+        cb.hint[0] = nch;
+        cb.hint[1] = (int32_t)n;
+        __threadfence_system();
+        cb.hint[2] = cb.seq;
     }
 }
 
@@ -2337,12 +2402,12 @@ uint32_t chain_table_size(int64_t n_cand) {
     return t;
 }
 
-hipError_t launch_setup(int64_t n, int P, int n_band, const double* params, const double* split, int numT, const ChainBufs& cb, int32_t* order,
+hipError_t launch_setup(const DevModel& m, int64_t n, const double* params, const double* split, const ChainBufs& cb, int32_t* order,
                         int64_t n_rep, const double* jsfs, double* consts, int unfolded, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     const int cand_blocks = (int)((n + 255) / 256);
     const int rep_blocks = (int)((n_rep + 255) / 256);
-    hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(cand_blocks + 1 + rep_blocks)), dim3(256), 0, stream, n, P, 2 * n_band, params, split, numT, cb,
+    hipLaunchKernelGGL(setup_kernel, dim3((unsigned)(cand_blocks + 1 + rep_blocks)), dim3(256), 0, stream, m, n, params, split, cb,
                        cand_blocks, order, n_rep, jsfs, consts, unfolded);
     return hipGetLastError();
 }
@@ -2414,13 +2479,25 @@ size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 
 // 2 per wave 5.4 ms; packing also executes fewer instructions in total, which is what counts when batches
 // overlap: 6.8 against 6.2 and 4.8 million evaluations/s for 10, 8 and 4 per wave.)  A chain's bits do not
 // depend on the packing (tests/test_gpu_trunk.py).
-int correct_cands_per_wave(int64_t n_items) {
-    const char* e = getenv("MISTI_CANDS_PER_WAVE");       // diagnostic override, read per call: tests toggle it
-    const int forced = e ? atoi(e) : 0;
+int correct_cands_per_wave(int64_t n_items, const Tuning& tn) {
+    const int forced = tn.cands_per_wave;
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 10) return forced;
     int cpw = 1;
     while (cpw < 8 && n_items / cpw > 2048) cpw *= 2;
     return cpw == 8 ? 10 : cpw;
+}
+
+Tuning read_tuning() {
+    Tuning t;
+    auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+    auto flag = [](const char* name) { const char* e = getenv(name); return e && e[0] && e[0] != '0'; };
+    t.chains_per_wave = num("MISTI_CHAINS_PER_WAVE");
+    t.cands_per_wave = num("MISTI_CANDS_PER_WAVE");
+    t.no_follow = flag("MISTI_NO_FOLLOW");
+    t.no_trunk = flag("MISTI_NO_TRUNK");
+    t.follow_max = num("MISTI_FOLLOW_MAX_CHAINS");
+    t.min_blocks = num("MISTI_FOLLOW_MIN_BLOCKS");
+    return t;
 }
 
 static size_t correct_lds_bytes(int numT) { return (size_t)(3 * numT - 1) * sizeof(double); }
@@ -2435,10 +2512,8 @@ static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs&
 
 // One chain per wavefront and a trunk to build: the trunk follows its chain inside the chain launch
 // (correct_follow_kernel) instead of running after it.  MISTI_NO_FOLLOW=1 keeps it in the post launch.
-bool trunk_follows(int cpw_chains, int64_t trunk_cap) {
-    const char* e = getenv("MISTI_NO_FOLLOW");
-    const bool off = e && e[0] && e[0] != '0';
-    return !off && trunk_cap > 0 && cpw_chains == 1;
+bool trunk_follows(int cpw_chains, int64_t trunk_cap, const Tuning& tn) {
+    return !tn.no_follow && trunk_cap > 0 && cpw_chains == 1;
 }
 
 template <bool CPFIT, int GROUP>
@@ -2464,17 +2539,20 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 // cpw: chains per wavefront, chosen by the caller from the expected number of chains
 // est_chains: chains of the previous batch of this size on the context, or < 0 when unknown
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, hipStream_t stream) {
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     if (follow) {
         const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT + 2 + 6 * (size_t)m.numT) * sizeof(double);
-        // one workgroup per chain expected (any grid is correct: workgroups stride over the chains); not n_cand
-        // workgroups of which all but n_chains leave at once (4 096 x 128 threads through the dispatcher for 64 chains)
+        // one workgroup per chain expected, at most the resident 1 024 (two waves per SIMD; 512 for the default fit at one): the
+        // workgroups pull chains from a queue, so any grid is correct and a stale hint costs at most idle or missing workgroups
         int64_t blocks = (est_chains > 0 && est_chains < n_cand) ? est_chains : n_cand;
-        // the hint may be stale (same batch size, other parameters): never fewer than 1 024 workgroups for a larger batch, so
-        // that a wrong guess costs at most a few chains in sequence per workgroup (idle workgroups leave at once)
-        const int64_t floor_blocks = n_cand < 1024 ? n_cand : 1024;
+        const int64_t resident = cp ? 1024 : 512;
+        if (blocks > resident) blocks = resident;
+        // the hint may be stale (same batch size, other parameters): never fewer than that many workgroups for a larger batch
+        // (idle workgroups find the queue empty and leave at once)
+        const int64_t min_blocks = tn.min_blocks > 0 ? tn.min_blocks : FOLLOW_MIN_BLOCKS;
+        const int64_t floor_blocks = n_cand < min_blocks ? n_cand : min_blocks;
         if (blocks < floor_blocks) blocks = floor_blocks;
         if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
         else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
@@ -2486,10 +2564,8 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 
 // chains the trunk buffer must hold for a batch of n_cand (the trunk runs only when
 // n_chains * TRUNK_MIN_SHARE <= n_cand); MISTI_NO_TRUNK=1 in the environment disables it
-int64_t trunk_capacity(int64_t n_cand) {
-    const char* e = getenv("MISTI_NO_TRUNK");              // read per call: tests toggle it
-    const bool off = e && e[0] && e[0] != '0';
-    if (off) return 0;
+int64_t trunk_capacity(int64_t n_cand, const Tuning& tn) {
+    if (tn.no_trunk) return 0;
     const int64_t cap = n_cand / TRUNK_MIN_SHARE;
     return cap < TRUNK_MAX_CHAINS ? cap : TRUNK_MAX_CHAINS;   // beyond that many chains candidates walk their own intervals
 }
@@ -2497,10 +2573,10 @@ int64_t trunk_capacity(int64_t n_cand) {
 // trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, hipStream_t stream) {
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, const Tuning& tn, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
-    const int cpw = correct_cands_per_wave(n_cand);              // tails: one item per candidate
+    const int cpw = correct_cands_per_wave(n_cand, tn);          // tails: one item per candidate
     MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream)
     if (!cp) {
         const int64_t threads = n_cand * (int64_t)(m.numT + 1);
