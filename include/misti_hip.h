@@ -221,6 +221,9 @@ int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
  *     bits 20-23 kind        0 no solve (trueEPS / T == 0), 1 closed form (SolveNoMigration1 :213-235,
  *                            cpfit post-split :366), 2 bounded TRF (SolveNoMigration :253-264, FitSinglePop
  *                            :82-92), 3 unbounded TRF (SolveLambdaSystem :299-305)
+ *     bit 24     noise       default fit: the solve went on past a gradient test (gtol) that its noise-free residual
+ *                            satisfied, because the reference's own residual - whose rounding noise is measured on the
+ *                            spot - would typically not have satisfied it
  * for intervals 0..numT (row numT is used only by a fractional split); and, for batches of at most
  * MISTI_TRACE_MAX_CAND candidates, the trial points of the unbounded solves (stretched to the unit
  * interval as the reference does, :293-298), at most MISTI_TRACE_MAX_ITER per interval.
@@ -230,6 +233,7 @@ int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
  *                                                          (NaN beyond nfev); row = interval on the
  *                                                          shared grid; the interval shortened by a
  *                                                          fractional split is not recorded */
+#define MISTI_TRACE_NOISE_BIT (1 << 24)
 #define MISTI_TRACE_MAX_CAND 64
 #define MISTI_TRACE_MAX_ITER 200
 int misti_enable_solver_trace(misti_ctx* ctx, int on);
