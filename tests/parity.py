@@ -90,17 +90,14 @@ def perturbed(times, lambdas, kind):
 # the reference's gain ratio is > 0.75 (radius doubled) and the HIP path's is not - numerator and denominator are both
 # rounding noise of a saturated residual there - and the two stop 8 iterations apart (profiles/r02_solver_traces.txt).
 # Kept as a test with its measured distance as the bound, reported as OUTSIDE by tools/parity_report.py.
-KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6,
-                 # Campaign seed 2, model 35 (default fit, one band over one interval): the chain's one migrating solve takes the
-                 # reference 3 evaluations and the HIP path 2 - (nfev 3) | (nfev 2) in profiles/r02_solver_traces.txt.  The
-                 # reference's residual M^-1 e^M p - M^-2 (e^M - I) p carries ~1e-14 of cancellation noise, its forward-difference
-                 # Jacobian (h = 1.5e-8) therefore ~1e-6, so its first Gauss-Newton step lands where |J^T f| is still above
-                 # gtol = 1e-10 and a third evaluation converges fully; the device's integral series has no such noise, its
-                 # first step already satisfies gtol and SciPy's test stops it there, 1e-7 short in the rate.  With the
-                 # reference's own formula on the device (-DMISTI_ECT_FORMULA) these four agree to 1e-11 ... 8e-11 - and 90 to
-                 # 120 other candidates per campaign move out to 1e-3 (its noise is then drawn twice): DESIGN.md section 2.
-                 "camp_s2_m35_c1": 5e-8, "camp_s2_m35_c9": 5e-8, "camp_s2_m35_c11": 5e-8, "camp_s2_m35_c21": 5e-8}
-
+KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6}
+# (Round 2 also listed camp_s2_m35_c{1,9,11,21} here - default fit, the reference's noisy residual taking one more evaluation than
+# the noise-free series: closed in round 3 by ect_noise_continues in misti_kernels.hip; they now agree to 3e-12 ... 1.1e-10.)
+# A third study of camp_m148_c12 (tests/golden/internal_noise.py --residual: one ulp of noise in the residual vector handed to
+# least_squares, 16 runs) moves the reference by 1.2e-8, and halving / doubling its solver tolerances by 1.1e-8 / 1.8e-8: the
+# reference DETERMINES this value to ~1.5e-8 and the HIP path misses it by 2.5e-7.  Its expm of the runaway interval's generator
+# (|M| = 1e5: 17 squarings) carries a systematic relative error of ~1e-11 that the exact two-state form used here does not have,
+# and the gain ratio of a saturated residual is decided below that.  Open.
 
 
 def determined(out):
@@ -140,3 +137,45 @@ def engine_args(case_in):
 def implemented(kw):
     """Modes the HIP path covers (grows as modes are added)."""
     return True
+
+
+# ---- the contract at test time, against the compiled CPU baseline ----------------------------------------------------
+def baseline_contract(w, idx, hip_llk, hip_status, hip_jafs=None, rep=0, threads=16, kinds=8):
+    """Per-candidate contract for the candidates `idx` of workload `w` (replicate `rep`), checked against the compiled CPU baseline
+    (oracle/cpu/misti_cpu.cpp: the reference's algorithm restated, pinned on the reference's golden vectors): llk within
+    llk_tol, else within SELF_FACTOR x that candidate's own spread under `kinds` 2^-48 perturbations of the inputs -
+    computed here, only for the candidates that need it.  Returns a report dict; `outside` / `mismatch` are positions in idx."""
+    from oracle.cpu_baseline import cpu_eval
+    idx = np.asarray(idx)
+    split = w.split_time[idx]
+    par = None if w.params is None else w.params[idx]
+    row = w.jsfs[rep:rep + 1]
+
+    def base(times, lh, sel):
+        return cpu_eval(times, lh, w.bands, w.pulses, w.flags, w.sample_date, split[sel], None if par is None else par[sel], row, w.n_param, threads=threads)
+    everything = np.arange(len(idx))
+    c_llk, c_jafs, c_st, c_run, _ = base(w.times, w.lh, everything)
+    h_llk, h_st = np.asarray(hip_llk)[idx], np.asarray(hip_status)[idx]
+    if h_llk.ndim == 2:
+        h_llk = h_llk[:, rep]
+    both = (c_st == 0) & (h_st == 0)
+    err = np.where(both, np.abs(h_llk - c_llk[:, 0]), 0.0)
+    tol = np.array([llk_tol(c_llk[k, 0], row[0], c_jafs[k], w.flags["unfolded"]) if both[k] else 0.0 for k in everything])
+    need = np.where((both & (err > tol)) | ((c_st == 0) != (h_st == 0)))[0]
+    spread = np.zeros(len(idx))
+    flips = np.zeros(len(idx), dtype=bool)
+    if len(need):
+        for kind in range(kinds):
+            T, L = perturbed(w.times, w.lh, kind)
+            p_llk, _, p_st, _, _ = base(T, L, need)
+            fin = (p_st == 0) & (c_st[need] == 0)
+            d = np.where(fin, np.abs(p_llk[:, 0] - c_llk[need, 0]), 0.0)
+            spread[need] = np.maximum(spread[need], d)
+            flips[need] |= (p_st == 0) != (c_st[need] == 0)
+    tight = both & (err <= tol)
+    selfb = both & ~tight & (err <= SELF_FACTOR * spread)
+    outside = both & ~tight & ~selfb
+    mismatch = ((c_st == 0) != (h_st == 0)) & ~flips
+    rel = np.where(both, err / np.maximum(np.abs(c_llk[:, 0]), 1e-300), 0.0)
+    return dict(n=len(idx), both=int(both.sum()), tight=int(tight.sum()), self_bound=int(selfb.sum()), outside=np.where(outside)[0], mismatch=np.where(mismatch)[0],
+                rel=rel, run=c_run, worst_tight=float(rel[tight].max()) if tight.any() else 0.0, base_llk=c_llk[:, 0], base_status=c_st, base_jafs=c_jafs)

@@ -14,32 +14,35 @@ from conftest import GOLDEN, ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed,n_expected", [(1, 7648), (2, 7694), (3, 7434)])
-def test_random_batches_against_the_oracle(seed, n_expected):
+# Measured on MI355X with this round's build (profiles/r03_random_campaign_seed{1,2,3}.txt): candidates within 1e-9 and the
+# candidates OUTSIDE the contract, pinned by index with their measured distance as the bound.
+MEASURED = {1: dict(n=7648, tight=5223, outside={1941: 1e-6}),       # model 148 candidate 12 (--cpfit runaway, golden camp_m148_c12: 2.5e-7)
+            2: dict(n=7694, tight=5363, outside={}),
+            3: dict(n=7434, tight=5119, outside={})}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_batches_against_the_oracle(seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import random_campaign as rc
+    want = MEASURED[seed]
     rng = np.random.default_rng(seed)
     cases = [rc.random_batch(rng) for _ in range(600)]
     n_jobs = sum(len(c["split"]) for c in cases)
     ref = rc.load_ref(os.path.join(GOLDEN, "campaign_seed%d.json.gz" % seed), 600, seed, n_jobs)
     rep = rc.compare(cases, ref)
     s = rep["stats"]
-    assert s["candidates"] == n_jobs == n_expected
-    # failure against value only where the reference itself flips under a 2^-48 perturbation
-    assert s["status_mismatch"] <= 3, rep["bad"][:5]
+    assert s["candidates"] == n_jobs == want["n"]
+    # failure against value only where the reference itself flips under a 2^-48 perturbation: none measured, none allowed
+    assert s["status_mismatch"] == 0, rep["bad"][:5]
     comparable = s["tight"] + s["self_bound"] + s["internal_bound"] + s["outside"]
-    assert comparable >= n_expected - 700                  # the rest fails on both sides (negative rates, failed corrections)
+    assert comparable >= want["n"] - 700                  # the rest fails on both sides (negative rates, failed corrections)
     # the contract per candidate (tests/parity.py): 1e-9 (+ rounding floor), or 10 x the reference's own spread under 4-64
-    # perturbations of 2^-48 for THAT candidate, or (the 162 candidates beyond twice that spread were studied) under one
-    # ulp in its own pair-chain expm (tests/golden/campaign_seed1.json.gz, tools/self_perturbation.py)
-    assert s["tight"] >= 0.70 * comparable
-    # Discrete stop/continue flips of SciPy's tests are rare events of the reference too (a few per thousand
-    # ill-conditioned solves): a candidate whose flip the 4-64 perturbed reference runs did not happen to sample lands
-    # outside.  The fixture was studied against one build; another rounding realisation moves which candidates those are,
-    # so a small number is tolerated here - all of them in the noise-driven class - and profiles/ reports the exact count.
-    assert s["outside"] <= comparable // 150, rep["outside"][:10]
+    # perturbations of 2^-48 for THAT candidate, or under one ulp in its own pair-chain expm
+    assert s["tight"] >= want["tight"] - comparable // 100, (s["tight"], want["tight"])
+    # OUTSIDE: the pinned candidates with their measured distance as the bound, plus at most two stop/continue flips that the
+    # reference's 4-64 perturbed runs did not sample (another build's rounding moves which candidates those are) - small ones
+    extra = [b for b in rep["outside"] if b[2] not in want["outside"]]
+    assert len(extra) <= 2, extra
     for rel, spread, idx, ci, k, split, run, cpfit, kinds, internal in rep["outside"]:
-        c = cases[ci]
-        default_mig = (not c["flags"]["cpfit"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
-        assert run >= 5.0 or default_mig or rel <= 1e-8, (idx, rel, spread, run)
-        assert rel <= 5e-2, (idx, rel)
+        assert rel <= want["outside"].get(idx, 1e-6), (idx, rel, spread, run)

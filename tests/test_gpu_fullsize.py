@@ -9,80 +9,63 @@ perturbations of the inputs, at test time."""
 import numpy as np
 import pytest
 
-from parity import SELF_FACTOR, llk_tol, perturbed
+from parity import baseline_contract
 
 pytestmark = pytest.mark.gpu
 
 
 def full_contract(w, idx, threads=16, kinds=8):
     from misti_amd.engine import Engine
-    from oracle.cpu_baseline import cpu_eval
     split = w.split_time[idx]
     par = None if w.params is None else w.params[idx]
     with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
         r = e.evaluate(split, par, w.jsfs[:1])
-
-    def base(times, lh, sel):
-        return cpu_eval(times, lh, w.bands, w.pulses, w.flags, w.sample_date, split[sel], None if par is None else par[sel], w.jsfs[:1], w.n_param,
-                        threads=threads)
-    everything = np.arange(len(idx))
-    c_llk, c_jafs, c_st, c_run, _ = base(w.times, w.lh, everything)
-    both = (c_st == 0) & (r.status == 0)
-    err = np.abs(r.llk[:, 0] - c_llk[:, 0])
-    tol = np.array([llk_tol(c_llk[k, 0], w.jsfs[0], c_jafs[k], w.flags["unfolded"]) if both[k] else 0.0 for k in everything])
-    need = np.where((both & (err > tol)) | ((c_st == 0) != (r.status == 0)))[0]
-    spread = np.zeros(len(idx))
-    flips = np.zeros(len(idx), dtype=bool)
-    if len(need):
-        for kind in range(kinds):
-            T, L = perturbed(w.times, w.lh, kind)
-            p_llk, _, p_st, _, _ = base(T, L, need)
-            fin = (p_st == 0) & (c_st[need] == 0)
-            d = np.where(fin, np.abs(p_llk[:, 0] - c_llk[need, 0]), 0.0)
-            spread[need] = np.maximum(spread[need], d)
-            flips[need] |= (p_st == 0) != (c_st[need] == 0)
-    tight = both & (err <= tol)
-    selfb = both & ~tight & (err <= SELF_FACTOR * spread)
-    outside = both & ~tight & ~selfb
-    mismatch = ((c_st == 0) != (r.status == 0)) & ~flips
-    rel = np.where(both, err / np.maximum(np.abs(c_llk[:, 0]), 1e-300), 0.0)
-    return dict(n=len(idx), both=int(both.sum()), tight=int(tight.sum()), self_bound=int(selfb.sum()), outside=np.where(outside)[0], mismatch=np.where(mismatch)[0],
-                rel=rel, run=c_run, worst_tight=float(rel[tight].max()) if tight.any() else 0.0)
+    sub = type(w)(w.name, w.times, w.lh, w.bands, w.pulses, w.n_param, w.flags, w.sample_date, split, par, w.truth, w.jsfs)
+    return baseline_contract(sub, np.arange(len(idx)), r.llk, r.status, threads=threads, kinds=kinds)
 
 
-def check(rep, min_tight_frac):
+def check(rep, min_tight_frac, max_outside):
+    """Guards = what was measured on MI355X with this round's build (profiles/r03_fullsize_contract.txt) minus 2 % / plus 2:
+    a regression in the speculation tree, the reduced pair chain or the trunk moves dozens of candidates and fails here."""
     assert len(rep["mismatch"]) == 0, rep["mismatch"][:10]
     assert rep["tight"] >= min_tight_frac * rep["both"], rep
-    # a stop/continue flip the eight perturbed runs did not sample: rare, small, and only where the corrected rate ran away
-    assert len(rep["outside"]) <= max(2, rep["both"] // 200), (len(rep["outside"]), rep["rel"][rep["outside"]][:10])
+    # OUTSIDE = beyond 10 x the baseline's spread under EIGHT perturbations: whole chains whose runaway --cpfit solve takes another
+    # gain-ratio branch than the reference's (the class of golden camp_m148_c12: 1e-6 where the reference holds 1e-8), plus at most
+    # one gtol flip of a regular candidate within rounding of the 1e-9 bound
+    assert len(rep["outside"]) <= max_outside, (len(rep["outside"]), rep["rel"][rep["outside"]][:10])
     for k in rep["outside"]:
-        # (or, for a well-conditioned candidate, a flip of SciPy's gtol test within rounding of its threshold: a few 1e-9)
-        assert rep["rel"][k] <= 1e-8 or (rep["rel"][k] <= 1e-3 and rep["run"][k] >= 5.0), (k, rep["rel"][k], rep["run"][k])
+        assert rep["rel"][k] <= 2e-9 or (rep["rel"][k] <= 1e-5 and rep["run"][k] >= 5.0), (k, rep["rel"][k], rep["run"][k])
 
 
 def test_headline_grid_every_candidate():
-    """BASELINE config 2 at full size: all 4 096 candidates of the 64 x 64 split x rate grid."""
+    """BASELINE config 2 at full size: all 4 096 candidates of the 64 x 64 split x rate grid.
+    Measured: 3 514 within 1e-9 (85.8 %), 571 within 10 x their spread, 11 outside - ONE chain (rate index 35, rate x length 1 846),
+    1.9e-6 ... 3.6e-6."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config2(lambda *a: truth_spectrum(*a))
     rep = full_contract(w, np.arange(w.n_cand))
-    check(rep, 0.80)
+    check(rep, 0.838, 13)
     assert rep["both"] == 4096 and rep["worst_tight"] <= 2e-9
+    assert len({int(k) % 64 for k in rep["outside"]}) <= 2          # whole chains, not scattered candidates
 
 
 def test_config5_sample_every_candidate():
-    """BASELINE config 5 (ancient second genome, band x pulse x split): 4 096 of the 65 536 candidates, evenly spaced."""
+    """BASELINE config 5 (ancient second genome, band x pulse x split): 4 096 of the 65 536 candidates, evenly spaced.
+    Measured: 3 210 of 4 080 within 1e-9 (78.7 %), 868 within 10 x their spread, 2 outside (one chain, 5e-6 ... 6e-6)."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config5(lambda *a: truth_spectrum(*a))
     rep = full_contract(w, np.arange(0, w.n_cand, 16))
-    check(rep, 0.45)
+    check(rep, 0.767, 4)
 
 
 def test_config3_sample_every_candidate():
-    """BASELINE config 3 (two optimised bands, random parameter vectors): 4 096 of the 16 384 starts."""
+    """BASELINE config 3 (two optimised bands, random parameter vectors): 4 096 of the 16 384 starts.
+    Measured: 3 705 of 4 078 within 1e-9 (90.9 %), 366 within 10 x their spread, 7 outside (six runaway starts at 4e-7 ... 5e-6,
+    one regular start at 1.3e-9)."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config3(lambda *a: truth_spectrum(*a))
     rep = full_contract(w, np.arange(0, w.n_cand, 4))
-    check(rep, 0.85)
+    check(rep, 0.888, 9)

@@ -3,7 +3,7 @@ oracle on a sample, and size-independent properties of the model on the whole ba
 import numpy as np
 import pytest
 
-from parity import llk_tol
+from parity import baseline_contract, llk_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -24,7 +24,7 @@ def cfg2():
 def test_grid_sample_against_oracle(cfg2):
     """BASELINE config 2 at full size (4 096 candidates, numT = 128) vs the oracle on 96
     evenly spaced candidates: statuses equal; llk within 1e-9 (+ rounding floor) wherever the
-    reference is determined; runaway-rate candidates (see oracle) within 1e-3."""
+    reference is determined; runaway-rate candidates under the per-candidate contract of tests/parity.py."""
     from oracle.batch import oracle_batch
     w, eng, res = cfg2
     idx = np.linspace(0, w.n_cand - 1, 96).astype(int)
@@ -45,9 +45,14 @@ def test_grid_sample_against_oracle(cfg2):
                 assert err <= 1e-7 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0])
             else:
                 np.testing.assert_allclose(res.jafs[c], oracle_batch.last_jafs[k], rtol=1e-9)
-        else:
-            assert err <= 1e-3 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0], run[k])
     assert n_reg >= 60 and n_out <= max(1, n_reg // 100)
+    # runaway-rate candidates: the per-candidate contract (1e-9, or 10 x that candidate's own spread under eight 2^-48
+    # perturbations, measured here through the compiled baseline).  Measured on MI355X: 82 tight, 13 within their spread, ONE
+    # outside (candidate 3 491 of the chain of rate index 35: 1.9e-6, rate x length 1 846)
+    rep = baseline_contract(w, idx, res.llk, res.status)
+    assert len(rep["mismatch"]) == 0 and len(rep["outside"]) <= 2, [(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]]
+    for k in rep["outside"]:
+        assert rep["run"][k] >= RUNAWAY and rep["rel"][k] <= 1e-5, (int(idx[k]), rep["rel"][k], rep["run"][k])
     # the engine's own diagnostic agrees with the oracle's measure of the same quantity
     ok = (o_st == 0)
     both_small = (run[ok] < 4.0) & (res.runaway[idx][ok] < 4.0)

@@ -27,10 +27,15 @@ def test_iteration_history(name):
     fd = r["first_diff"]
     assert r["max_rel_before"] <= 1e-5, r                        # trial points of the solves before the first differing one
     if name.startswith("camp_s2_m35"):
-        # documented outlier (tests/parity.py: KNOWN_OUTSIDE): exactly one solve differs - the migrating interval of the
-        # default fit, three evaluations in the reference, two on the device
-        assert name in KNOWN_OUTSIDE and fd is not None and fd["site"] == "two_pop_ect" and fd["ref"] == (3, 1) and fd["hip"] == (2, 1), r
-        assert r["n_equal"] == r["n_solves"] - 1, r
+        # round 2's documented outlier: the migrating interval of the default fit took the reference three evaluations and the
+        # device two (its noise-free residual satisfied gtol one evaluation early).  Now the same iteration, solve by solve -
+        # and the solver word says why (bit 24: went on past a gradient test only the reference's noisy residual fails)
+        assert name not in KNOWN_OUTSIDE and fd is None and r["n_equal"] == r["n_solves"], r
+        from solver_trace_util import hip_trace
+        _, _, tr = hip_trace(case)
+        sv = [s for s in ref["solves"] if s["site"] == "two_pop_ect"]
+        assert len(sv) == 1 and (sv[0]["nfev"], sv[0]["status"]) == (3, 1)
+        assert int(tr["noise"][0, sv[0]["t"]]) == 1 and int(tr["nfev"][0, sv[0]["t"]]) == 3
         return
     if determined(case["out"]):
         assert fd is None and r["n_equal"] == r["n_solves"], r   # the same iteration, solve by solve
