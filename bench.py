@@ -162,13 +162,45 @@ def follow_limit():
         return 256
 
 
+def smoothing_runs(lh, k):
+    """(run_start[t], run_end[t]) of genome k: greedy runs of numerically constant lh, as SmoothConst scans them
+    (/root/reference/MigrationInference.py:387-405; misti_api.cpp: smoothing_runs)."""
+    numT = len(lh)
+    rs, re, i = [0] * numT, [0] * numT, 0
+    while i < numT:
+        j = i
+        while j < numT - 1 and abs(lh[j][k] - lh[i][k]) < 1e-10:
+            j += 1
+        if j == i:
+            j = i + 1
+        for t in range(i, j):
+            rs[t], re[t] = i, j
+        i = j
+    return rs, re
+
+
+def trunk_leave_index(w, runs, st):
+    """First interval whose rates depend on this candidate's split (misti_kernels.hip: trunk_leave): where it reads its chain's trunk."""
+    s = int(np.floor(st))
+    frac = st != s
+    t_own = s
+    if w.flags.get("smooth"):
+        if frac:
+            t_own = min(runs[0][0][s], runs[1][0][s])
+        elif s > 0:
+            for k in (0, 1):
+                if runs[k][1][s - 1] > s:
+                    t_own = min(t_own, runs[k][0][s - 1])
+    return t_own
+
+
 def algorithmic_bytes(w, n_rep, idx=None):
     """HBM bytes the algorithm needs per launch, per kernel.
 
     correction: one chain per distinct parameter vector, computed up to the largest split index of
                 its members: 8P in; per interval 16 B of rates + 48 B of pair state out (+ the trunk records,
-                1 056 B per chain and interval from the first interval a member reads, when the trunk wave follows
-                its chain in the same launch);
+                1 056 B per chain and distinct interval at which a member leaves the trunk, when the trunk wave
+                follows its chain in the same launch);
     spectrum:   per candidate split 8 + params 8P in, its share of the chain 16 B per two-population
                 interval + 48 B state, JAFS 56 + status 4 out (+ one trunk record of 1 056 B when chains are
                 shared; the trunk launch itself writes one record per chain and interval);
@@ -181,7 +213,11 @@ def algorithmic_bytes(w, n_rep, idx=None):
     correct = sum(8 * P + 64 * L for L in chains.values())
     spectrum = int((8 + 8 * P + 16 * s_int + 48 + 60).sum())
     if len(chains) * 8 <= n:                                  # TRUNK_MIN_SHARE (misti_consts.h): chains are shared, a trunk is built
-        trunk = sum(1056 * (L + 1) for L in chains.values())
+        # the trunk of a chain hands over one record (state vector + two occupation integrals, 1 056 B) per DISTINCT interval at which
+        # some member leaves it
+        runs = [smoothing_runs(w.lh, k) for k in (0, 1)]
+        key = (lambda i: tuple(w.params[i])) if w.params is not None else (lambda i: ())
+        trunk = 1056 * len({(key(i), trunk_leave_index(w, runs, float(w.split_time[i]))) for i in sel})
         spectrum += 1056 * n                                  # one trunk record per candidate
         if len(chains) <= follow_limit():                     # one chain per wave: the trunk wave follows its chain inside the chain launch
             correct += trunk
@@ -435,6 +471,62 @@ def main():
                 lane.close()
         return res
 
+    def host_abi_leg(workload, k):
+        """The C ABI's HOST-buffer form, misti_eval_batch (pageable NumPy arrays in and out, as a ctypes caller of the reference
+        would hold them; PCIe both ways inside the call, which returns when the results are in the caller's memory): K calls
+        one after another on one context, then K calls from two host threads on two contexts (the copies of one batch
+        overlap the kernels of the other; ctypes releases the GIL for the duration of a call)."""
+        import ctypes as C
+        import threading
+        from misti_amd import _lib as L
+        w = build_workload(workload, spec)
+        n, R, P = w.n_cand, int(w.jsfs.shape[0]), w.n_param
+        lib = L.load()
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+        class Ctx:
+            def __init__(self):
+                self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
+                self.split = np.ascontiguousarray(w.split_time, dtype=np.float64)
+                self.par = np.ascontiguousarray(w.params, dtype=np.float64) if P else None
+                self.rows = np.ascontiguousarray(w.jsfs, dtype=np.float64)
+                self.llk, self.jafs, self.status = np.empty((n, R)), np.empty((n, 7)), np.empty(n, dtype=np.int32)
+
+            def call(self):
+                L.check(lib.misti_eval_batch(self.eng._ctx, n, ptr(self.split), ptr(self.par), None, R, ptr(self.rows), ptr(self.llk), ptr(self.jafs),
+                                             None, None, ptr(self.status)))
+
+        a_, b_ = Ctx(), Ctx()
+        for c in (a_, b_):
+            for _ in range(3):
+                c.call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            a_.call()
+        serial = (time.perf_counter() - t0) / k
+
+        def worker(c, m):
+            for _ in range(m):
+                c.call()
+        th = [threading.Thread(target=worker, args=(c, k // 2)) for c in (a_, b_)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        both = (time.perf_counter() - t0) / (2 * (k // 2))
+        ok = float((a_.status == 0).mean())
+        in_b = 8 * n * (1 + P) + 64 * R
+        out_b = 8 * n * R + 56 * n + 4 * n
+        a_.eng.close(); b_.eng.close()
+        return {"workload": w.name, "entry_point": "misti_eval_batch (host buffers, pageable; pinned staging inside the library)",
+                "ms_per_batch": 1e3 * serial, "value": n * R / serial, "unit": "llk evals/s", "calls": k, "contexts": 1,
+                "two_contexts": {"ms_per_batch": 1e3 * both, "value": n * R / both, "contexts": 2, "host_threads": 2,
+                                 "note": "two host threads, one context each: the copies of one batch overlap the kernels of the other"},
+                "bytes_in": in_b, "bytes_out": out_b, "status_ok_fraction": ok,
+                "note": "PCIe-inclusive: never `value` of the line; compare with single_batch (device-resident inputs, same grid)"}
+
     def block(res, note=None):
         """A secondary leg as a JSON block."""
         b = {"workload": res["w"].name, "value": res["value"], "unit": "llk evals/s", "ms_per_step": 1e3 * res["dt"] / res["steps"], "steps": res["steps"],
@@ -493,6 +585,7 @@ def main():
             s_leg = leg("config2x16", "weak", max(4, min(a.steps, 32)), 4, a.min_seconds, 1, serial_pass=True)
             extra["single_call"] = block(s_leg, "16 config-2 grids with distinct rate axes (65 536 candidates, 1 024 chains) as ONE misti_eval_batch_dev "
                                                 "call per step, strictly one after another on ONE stream")
+            extra["host_abi"] = host_abi_leg("config2", max(16, min(a.steps, 128)))
 
     if rank == 0:
         out.update(extra)
@@ -571,9 +664,13 @@ def main():
 
 
 def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
-    """`roofline` of the dominant kernel.  HBM: algorithmic bytes / HIP-event duration (measured in this run) against 8 TB/s, with the
-    counter traffic of the same kernel from profiles/pmc_latest.json (rocprofv3 --pmc passes of the same command; stored, keyed
-    by workload).  VALU: what actually binds - wave-instructions issued against the chip's issue slots."""
+    """`roofline` of the dominant kernel.
+
+    The contract's bounds are hbm | mfma; neither binds this path (~1 KB and ~1e5 dependent fp64 operations per
+    candidate, 3x3 / sparse 44x44 matrices).  What binds is fp64 VALU issue: the top level reports THAT (bound "valu":
+    wave-instructions issued x 4 cycles against 1 024 SIMDs x clock), `hbm` carries the figures the contract asks for
+    (algorithmic bytes / HIP-event duration against 8 TB/s, counter traffic), `valu` the raw counters.  Durations are HIP events
+    of this run; the counters are rocprofv3 --pmc passes of the same command, stored per workload in profiles/pmc_latest.json."""
     traffic, traffic_source, valu = None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc) and world == 1:
@@ -584,29 +681,36 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
                 traffic = j.get(dom + "_hbm_bytes_per_launch")
                 traffic_source = "stored: profiles/pmc_latest.json <- " + str(j.get("source")) + " (not measured in this run)"
                 v = j.get(dom + "_valu")
-                if v and per_ms[dom] > 0:
+                if v and v.get("SQ_INSTS_VALU") and per_ms[dom] > 0:
                     # 4 SIMDs x 256 CUs; a wave-instruction in fp64 occupies its SIMD's VALU for 4 cycles (16 lanes per cycle)
                     cycles = per_ms[dom] * 1e-3 * GPU_CLOCK_HZ
-                    valu = {"wave_insts": v.get("SQ_INSTS_VALU"), "lane_occupancy": v.get("lane_occupancy"),
-                            "frac": 4.0 * v["SQ_INSTS_VALU"] / (N_SIMD * cycles) if v.get("SQ_INSTS_VALU") else None,
-                            "kernel_cycles": cycles, "clock_hz": GPU_CLOCK_HZ, "simds": N_SIMD,
+                    valu = {"wave_insts": v["SQ_INSTS_VALU"], "lane_occupancy": v.get("lane_occupancy"),
+                            "frac": 4.0 * v["SQ_INSTS_VALU"] / (N_SIMD * cycles),
+                            "kernel_cycles": cycles, "clock_hz": GPU_CLOCK_HZ, "simds": N_SIMD, "kernel": v.get("kernel"),
                             "waves_launched": v.get("SQ_WAVES"), "busy_cycles": v.get("SQ_BUSY_CYCLES"),
-                            "source": "SQ counters stored in profiles/pmc_latest.json (rocprofv3 --pmc pass of this command), duration measured in this run",
-                            "note": "frac = 4 x SQ_INSTS_VALU / (1 024 SIMDs x kernel cycles): share of the chip's fp64 VALU issue slots this launch used"}
+                            "issue_stall_share": (v["SQ_WAIT_INST_ANY"] / v["SQ_WAVE_CYCLES"]) if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAIT_INST_ANY") is not None else None,
+                            "source": "SQ counters stored in profiles/pmc_latest.json (rocprofv3 --pmc passes of this command), duration measured in this run",
+                            "note": "frac = 4 x SQ_INSTS_VALU / (1 024 SIMDs x kernel cycles at 2.4 GHz): share of the chip's fp64 VALU issue slots this launch "
+                                    "used; lane_occupancy = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes live per issued instruction (wave-uniform "
+                                    "bookkeeping of a chain runs in all 64 lanes: live, not useful)"}
         except Exception:
-            traffic = None
-    bound = "hbm"
-    blk = {"bound": bound, "kernel": dom + "_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-           "algorithmic_bytes_per_launch": ab[dom], "candidates_per_launch": n, "chains_per_launch": ab["n_chains"],
-           "ms_per_launch": per_ms,
-           "binding_resource": "dependent fp64 VALU issue of the longest lambda-correction chain (latency), not HBM and not MFMA",
-           "note": "the contract's two bounds are hbm | mfma; neither binds this path (SURVEY 8d): ~1 KB per candidate against ~1e5 dependent fp64 "
-                   "operations.  The hbm fraction is reported as asked; `valu` is the resource that binds: the correction kernel by the "
-                   "dependent-issue latency of its longest chain (serial trust-region iterations of the reference's solver), the spectrum "
-                   "kernel by fp64 VALU issue + LDS latency"}
+            traffic, valu = None, None
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+           "algorithmic_bytes_per_launch": ab[dom]}
+    common = {"kernel": dom + "_kernel", "candidates_per_launch": n, "chains_per_launch": ab["n_chains"], "ms_per_launch": per_ms, "traffic": traffic,
+              "traffic_source": traffic_source, "algorithmic_bytes_per_launch": ab[dom], "hbm": hbm,
+              "binding_resource": "fp64 VALU issue: the dependent instruction stream of each lambda-correction chain (serial trust-region iterations of the "
+                                  "reference's solver) - latency-bound with few chains per launch, issue-bound with many; not HBM, not MFMA"}
     if valu:
-        blk["valu"] = valu
+        peak = N_SIMD * GPU_CLOCK_HZ
+        blk = {"bound": "valu", "achieved": valu["frac"] * peak, "peak": peak, "unit": "fp64 VALU issue cycles/s (wave-instructions x 4)", "frac": valu["frac"],
+               "valu": valu,
+               "note": "the contract's two bounds are hbm | mfma and neither binds (SURVEY 8d); `hbm` below carries the HBM figures as asked, the top level "
+                       "the resource that binds"}
+    else:
+        blk = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "note": "no stored SQ counters for this workload: HBM figures only; the path is bound by fp64 VALU issue latency, not by HBM (SURVEY 8d)"}
+    blk.update(common)
     return blk
 
 

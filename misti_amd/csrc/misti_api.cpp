@@ -59,6 +59,23 @@ struct DevBuf {
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 
+// Host-pinned staging of the host-buffer entry points: a copy from / to pageable memory makes the runtime stage the bytes itself
+// and wait; from pinned memory hipMemcpyAsync is a DMA the stream orders like a kernel.
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipHostFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+constexpr size_t PIN_STAGE_MAX = (size_t)256 << 20;    // beyond this the host-buffer calls copy straight from / to the caller's memory
+
 }  // namespace
 
 struct misti_ctx {
@@ -82,6 +99,7 @@ struct misti_ctx {
     DevBuf ws_trunk;                    // per chain: 44-state records before every interval (trunk kernel -> kernel 2)
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_bounds, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
+    PinBuf pin_in, pin_out;             // pinned staging of misti_eval_batch: inputs packed, outputs packed
     bool trace = false;                 // solver trace (misti_enable_solver_trace)
     DevBuf ws_solver, ws_iters;         // per chain / per candidate solver words; trial points of small batches
     DevBuf ws_post;                     // default fit: rates after the split per candidate and interval (+ their solver words)
@@ -466,6 +484,26 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
             std::memcpy(runs.data() + k * numT, rs.data(), sizeof(int) * numT);
             std::memcpy(runs.data() + (2 + k) * numT, re.data(), sizeof(int) * numT);
         }
+        {
+            // Where can a candidate leave its chain's trunk?  (trunk_leave in misti_kernels.hip, for every split an integer or a
+            // fractional split time can produce.)  A function of the smoothing runs alone: the trunk stores records only there.
+            const int* rs0 = runs.data(), *rs1 = runs.data() + numT, *re0 = runs.data() + 2 * numT, *re1 = runs.data() + 3 * numT;
+            std::vector<int> ok((size_t)numT, 0);
+            const bool smooth = (model->flags & MISTI_SMOOTH) != 0;
+            for (int s = 0; s < numT; ++s) {
+                int frac_own = s, int_own = s;
+                if (smooth) {
+                    frac_own = rs0[s] < rs1[s] ? rs0[s] : rs1[s];               // the interval s is split in two
+                    if (s > 0) {
+                        if (re0[s - 1] > s && rs0[s - 1] < int_own) int_own = rs0[s - 1];
+                        if (re1[s - 1] > s && rs1[s - 1] < int_own) int_own = rs1[s - 1];
+                    }
+                }
+                ok[(size_t)frac_own] = 1;
+                ok[(size_t)int_own] = 1;
+            }
+            runs.insert(runs.end(), ok.begin(), ok.end());
+        }
         HIP_TRY(c->model_i32.reserve(runs.size() * sizeof(int)));
         HIP_TRY(hipMemcpy(c->model_i32.p, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
         misti::DevModel& d = c->dm;
@@ -478,6 +516,7 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
         d.lh = d.times + (numT - 1);
         d.run_start = c->model_i32.as<int>();
         d.run_end = d.run_start + 2 * numT;
+        d.leave_ok = d.run_start + 4 * numT;
         for (int b = 0; b < model->n_band; ++b) d.bands[b] = model->bands[b];
         for (int p = 0; p < model->n_pulse; ++p) d.pulses[p] = model->pulses[p];
         c->unfolded = (model->flags & MISTI_UNFOLDED) ? 1 : 0;
@@ -497,6 +536,8 @@ int misti_destroy(misti_ctx* c) {
                     &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    c->pin_in.release();
+    c->pin_out.release();
     c->nm_f64.release();
     c->nm_i32.release();
     if (c->nm_live_host) (void)hipHostFree(c->nm_live_host);
@@ -580,26 +621,35 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
     if (n_rep > 0 && (!jsfs || !llk)) return fail(MISTI_E_ARG, "jsfs / llk is NULL with n_rep > 0");
     HIP_TRY(hipSetDevice(c->device));
     const size_t nc = (size_t)n_cand, nr = (size_t)n_rep;
-    HIP_TRY(c->st_split.reserve(nc * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(c->st_split.p, split, nc * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if (P > 0) {
-        HIP_TRY(c->st_params.reserve(nc * P * sizeof(double)));
-        HIP_TRY(hipMemcpyAsync(c->st_params.p, params, nc * P * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    }
     const bool with_bounds = band_bounds && c->dm.n_band > 0;
-    if (with_bounds) {
-        const size_t bytes = nc * 2 * (size_t)c->dm.n_band * sizeof(int32_t);
-        HIP_TRY(c->st_bounds.reserve(bytes));
-        HIP_TRY(hipMemcpyAsync(c->st_bounds.p, band_bounds, bytes, hipMemcpyHostToDevice, c->stream));
-    }
-    if (nr) {
-        HIP_TRY(c->st_jsfs.reserve(nr * 8 * sizeof(double)));
-        HIP_TRY(hipMemcpyAsync(c->st_jsfs.p, jsfs, nr * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c->st_llk.reserve(nc * nr * sizeof(double)));
-    }
+    const size_t b_split = nc * sizeof(double), b_par = P > 0 ? nc * P * sizeof(double) : 0;
+    const size_t b_bounds = with_bounds ? nc * 2 * (size_t)c->dm.n_band * sizeof(int32_t) : 0, b_jsfs = nr * 8 * sizeof(double);
+    const size_t lc_n = nc * (size_t)(numT + 1) * 2, pr_n = nc * (size_t)(numT + 2) * 6;
+    const size_t b_llk = nr ? nc * nr * sizeof(double) : 0, b_jafs = jafs ? nc * 7 * sizeof(double) : 0, b_lc = lc ? lc_n * sizeof(double) : 0;
+    const size_t b_pr = pr ? pr_n * sizeof(double) : 0, b_status = status ? nc * sizeof(int32_t) : 0;
+    const size_t in_bytes = b_split + b_par + b_bounds + b_jsfs, out_bytes = b_llk + b_jafs + b_lc + b_pr + b_status;
+    // The caller's buffers are pageable: inputs are packed into ONE pinned block (a CPU memcpy of tens of KB), copied by truly
+    // asynchronous DMAs; outputs come back into one pinned block and are handed over after the single wait at the end.
+    const bool pinned = in_bytes <= PIN_STAGE_MAX && out_bytes <= PIN_STAGE_MAX &&
+                        c->pin_in.reserve(in_bytes) == hipSuccess && c->pin_out.reserve(out_bytes ? out_bytes : 8) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    char* hin = pinned ? static_cast<char*>(c->pin_in.p) : nullptr;
+    auto h2d = [&](DevBuf& dst, const void* src, size_t bytes, size_t& off) -> int {
+        if (!bytes) return 0;
+        HIP_TRY(dst.reserve(bytes));
+        const void* from = src;
+        if (pinned) { std::memcpy(hin + off, src, bytes); from = hin + off; off += bytes; }
+        HIP_TRY(hipMemcpyAsync(dst.p, from, bytes, hipMemcpyHostToDevice, c->stream));
+        return 0;
+    };
+    size_t off = 0;
+    if (int r = h2d(c->st_split, split, b_split, off)) return r;
+    if (int r = h2d(c->st_params, params, b_par, off)) return r;
+    if (int r = h2d(c->st_bounds, band_bounds, b_bounds, off)) return r;
+    if (int r = h2d(c->st_jsfs, jsfs, b_jsfs, off)) return r;
+    if (nr) HIP_TRY(c->st_llk.reserve(nc * nr * sizeof(double)));
     HIP_TRY(c->st_jafs.reserve(nc * 7 * sizeof(double)));
     HIP_TRY(c->st_status.reserve(nc * sizeof(int32_t)));
-    const size_t lc_n = nc * (size_t)(numT + 1) * 2, pr_n = nc * (size_t)(numT + 2) * 6;
     if (lc) HIP_TRY(c->st_lc.reserve(lc_n * sizeof(double)));
     if (pr) {
         HIP_TRY(c->st_pr.reserve(pr_n * sizeof(double)));
@@ -610,12 +660,25 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
                     nr ? c->st_jsfs.as<double>() : nullptr, nr ? c->st_llk.as<double>() : nullptr, c->st_jafs.as<double>(),
                     lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
     if (r) return r;
-    if (nr) HIP_TRY(hipMemcpyAsync(llk, c->st_llk.p, nc * nr * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (jafs) HIP_TRY(hipMemcpyAsync(jafs, c->st_jafs.p, nc * 7 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (lc) HIP_TRY(hipMemcpyAsync(lc, c->st_lc.p, lc_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (pr) HIP_TRY(hipMemcpyAsync(pr, c->st_pr.p, pr_n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (status) HIP_TRY(hipMemcpyAsync(status, c->st_status.p, nc * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    char* hout = pinned ? static_cast<char*>(c->pin_out.p) : nullptr;
+    struct Back { void* user; size_t off, bytes; };
+    Back back[5];
+    int n_back = 0;
+    size_t ooff = 0;
+    auto d2h = [&](void* user, const void* src, size_t bytes) -> int {
+        if (!bytes) return 0;
+        void* to = user;
+        if (pinned) { to = hout + ooff; back[n_back++] = {user, ooff, bytes}; ooff += bytes; }
+        HIP_TRY(hipMemcpyAsync(to, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    };
+    if (int q = d2h(llk, c->st_llk.p, b_llk)) return q;
+    if (int q = d2h(jafs, c->st_jafs.p, b_jafs)) return q;
+    if (int q = d2h(lc, c->st_lc.p, b_lc)) return q;
+    if (int q = d2h(pr, c->st_pr.p, b_pr)) return q;
+    if (int q = d2h(status, c->st_status.p, b_status)) return q;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n_back; ++i) std::memcpy(back[i].user, hout + back[i].off, back[i].bytes);
     return 0;
 }
 

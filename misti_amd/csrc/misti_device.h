@@ -39,6 +39,8 @@ struct DevModel {
     const double* lh;        // [numT][2]
     const int* run_start;    // [2][numT]  smoothing runs of constant lh (MigrationInference.py:387-405)
     const int* run_end;      // [2][numT]
+    const int* leave_ok;     // [numT]     1 where SOME split (integer or fractional) leaves a chain's trunk (trunk_leave): the only intervals
+                             //            whose trunk record a candidate can ever read
     misti_band_t bands[MISTI_MAX_BANDS];
     misti_pulse_t pulses[MISTI_MAX_PULSES];
 };

@@ -1967,8 +1967,10 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     double x = (lane == 2) ? 1.0 : 0.0;
     double w_pre = 0.0, w_post = 0.0;
     double* rec = cb.trunk + ch * (int64_t)m.numT * TRUNK_REC;
-    // records are read from the first interval at which a member leaves the trunk (setup_kernel: slot_keep) - and at the
-    // interval the trunk ends on, wherever that is: a third of the records of a split x rate grid is never read
+    // Records are read from the first interval at which a member leaves the trunk (setup_kernel: slot_keep), only at intervals
+    // where SOME split can leave it (m.leave_ok: with smoothing, starts of the runs a split can cut - a function of the model,
+    // computed in misti_create) - and at the interval the trunk ends on, wherever that is.  On the headline grid a third of the
+    // records lies before the first split and three quarters of the rest inside runs: never read, no longer written.
     const int t_first = m.numT - cb.slot_keep[cb.chain_slot[ch]];
     auto store = [&](int t, double xs, double ws0, double ws1) {
         if (R.live) { double* r = rec + (int64_t)t * TRUNK_REC; r[lane] = xs; r[NS2 + lane] = ws0; r[2 * NS2 + lane] = ws1; }
@@ -1978,7 +1980,7 @@ void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ pa
     double xs = x, ws0 = w_pre, ws1 = w_post;
     for (int t = 0; t < m.numT; ++t) {
         xs = x; ws0 = w_pre; ws1 = w_post;
-        stored = t >= t_first;
+        stored = t >= t_first && m.leave_ok[t] != 0;
         if (stored) store(t, xs, ws0, ws1);
         ok = t;
         if (t >= Lt) break;
@@ -2028,7 +2030,7 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
     long long spins = 0;
     for (int t = 0; t < m.numT; ++t) {
         xs = x; ws0 = w_pre; ws1 = w_post;
-        stored = t >= t_first;
+        stored = t >= t_first && m.leave_ok[t] != 0;
         if (stored) store(t, xs, ws0, ws1);
         ok = t;
         if (t >= len) break;

@@ -3,10 +3,11 @@
 
     profiles/<tag>_bench.json                  the default bench line (16 streams)
     profiles/<tag>_bench_serial.json           bench.py --streams 1 (what roofline.ms_per_launch is measured on)
-    profiles/<tag>_kernel_stats_serial.csv     rocprofv3 --kernel-trace --stats of bench.py --streams 1
+    profiles/<tag>_kernel_stats_serial_<workload>.csv   rocprofv3 --kernel-trace --stats of bench.py --workload W --streams 1
     profiles/<tag>_kernel_stats_pipelined.csv  the same for the default (overlapped launches run longer each)
-    profiles/<tag>_pmc.json                    per-kernel counters (separate --pmc passes)
-    profiles/pmc_latest.json                   HBM bytes per launch of the two big kernels (bench.py's roofline.traffic)
+    profiles/<tag>_pmc_<workload>.json         per-kernel counters (separate --pmc passes), config2 / config2x16 / config3 / config5
+    profiles/pmc_latest.json                   per workload: HBM bytes and SQ counters per launch of the two big kernels
+                                               (bench.py's roofline.traffic and roofline.valu)
 
     python tools/summarize_profiles.py r01
 """
@@ -62,44 +63,68 @@ def pmc_last(src_dir):
     return out
 
 
+WORKLOADS = ("config2", "config2x16", "config3", "config5")
+KERNEL1 = {"config2": "misti::correct_follow_kernel", "config2x16": "misti::correct_follow_kernel",
+           "config3": "misti::correct_kernel<true, 6>", "config5": "misti::correct_kernel<true, 6>"}
+
+
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for a, b in (("bench.json", "_bench.json"), ("bench_serial.json", "_bench_serial.json"), ("bench_config3.json", "_bench_config3.json"),
-                 ("bench_config4.json", "_bench_config4.json"), ("bench_config5.json", "_bench_config5.json"),
-                 ("bench_config3_search.json", "_bench_config3_search.json"), ("bench_dist_weak.json", "_bench_dist_weak_1rank.json"),
+                 ("bench_config4.json", "_bench_config4.json"), ("bench_config5.json", "_bench_config5.json"), ("bench_config2x16.json", "_bench_config2x16.json"),
+                 ("bench_config3_search.json", "_bench_config3_search.json"), ("bench_config3_basinhopping.json", "_bench_config3_basinhopping.json"),
+                 ("bench_dist_weak.json", "_bench_dist_weak_1rank.json"),
                  ("bench_dist_strong_config4.json", "_bench_dist_strong_config4_1rank.json"),
                  ("bench_dist_strong_config5.json", "_bench_dist_strong_config5_1rank.json")):
         p = os.path.join(src, a)
         if os.path.exists(p) and os.path.getsize(p):
-            line = [l for l in open(p) if l.startswith("{")][-1]
-            json.dump(json.loads(line), open(os.path.join(dst, tag + b), "w"), indent=1)
-            print("wrote", tag + b)
-    stats_csv(os.path.join(src, "trace_serial"), os.path.join(dst, tag + "_kernel_stats_serial.csv"))
+            lines = [l for l in open(p) if l.startswith("{")]
+            if lines:
+                json.dump(json.loads(lines[-1]), open(os.path.join(dst, tag + b), "w"), indent=1)
+                print("wrote", tag + b)
+    for wl in WORKLOADS:
+        stats_csv(os.path.join(src, "trace_serial_" + wl), os.path.join(dst, "%s_kernel_stats_serial_%s.csv" % (tag, wl)))
     stats_csv(os.path.join(src, "trace_pipelined"), os.path.join(dst, tag + "_kernel_stats_pipelined.csv"))
-    counters = {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
-        for k, d in pmc_last(os.path.join(src, sub)).items():
-            counters.setdefault(k, {}).update(d)
-    if counters:
-        note = ("rocprofv3 --pmc passes (separate runs: FETCH_SIZE / WRITE_SIZE / SQ_*) of `bench.py --streams 1 --steps 4` "
-                "(config 2, 4096 candidates, numT=128); values of each kernel's last launch (a timed bench batch). "
+    latest = {"note": "per workload: HBM bytes per launch of the two big kernels (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, KB -> bytes) and the SQ "
+                      "counters of the same launches; bench.py reads this for roofline.traffic and roofline.valu (stored, not measured in the bench run)",
+              "workloads": {}}
+    for wl in WORKLOADS:
+        counters = {}
+        for sub in ("pmc_fetch_", "pmc_write_", "pmc_sq_", "pmc_sq2_"):
+            for k, d in pmc_last(os.path.join(src, sub + wl)).items():
+                counters.setdefault(k, {}).update(d)
+        if not counters:
+            continue
+        note = ("rocprofv3 --pmc passes (separate runs: FETCH_SIZE / WRITE_SIZE / SQ_* / SQ_THREAD_CYCLES_VALU ...) of `bench.py --workload %s --streams 1 --steps 4 "
+                "--no-extra-legs`; values of each kernel's last launch (a timed bench batch). "
                 "FETCH_SIZE / WRITE_SIZE are KB as rocprofv3 reports them; on gfx950 FETCH_SIZE counts wide coalesced reads at half "
-                "their bytes (MI355X_MICROARCH.md, HBM section): doubled before comparing with a byte count.")
-        json.dump({"note": note, "counters": counters}, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
-        hbm = {}
-        # kernel 1 of the timed batches: the chain launch with the trunk following (first batch of a context: plain)
-        k1 = "misti::correct_follow_kernel" if any(k.startswith("misti::correct_follow_kernel") for k in counters) else "misti::correct_kernel<true, 64"
-        for key, pat in (("correct", k1), ("post", "misti::post_kernel"), ("spectrum", "misti::spectrum_kernel<true>")):
+                "their bytes (MI355X_MICROARCH.md, HBM section): doubled before comparing with a byte count. SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                "SQ_ACTIVE_INST_* count quad-cycles, SQ_INSTS_* instructions per wave." % wl)
+        json.dump({"note": note, "workload": wl, "counters": counters}, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
+        entry = {"source": "profiles/%s_pmc_%s.json" % (tag, wl)}
+        for key, pat in (("correct", KERNEL1[wl]), ("post", "misti::post_kernel"), ("spectrum", "misti::spectrum_kernel<true>")):
             for k, d in counters.items():
-                if k.startswith(pat) and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                    hbm[key + "_hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-        json.dump({"workload": "config2",
-                   "source": "profiles/%s_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KB -> bytes)" % tag, **hbm},
-                  open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
-        print("wrote", tag + "_pmc.json, pmc_latest.json:", hbm)
+                if not k.startswith(pat):
+                    continue
+                if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                    entry[key + "_hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+                if "SQ_INSTS_VALU" in d:
+                    v = {c: d[c] for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+                                           "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY") if c in d}
+                    if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
+                        # mean share of the 64 lanes a VALU instruction had live.  Both counters tick once per 4-cycle issue (the spectrum
+                        # kernel, 44 live lanes of 64 in its main loop and fewer around it, reads 0.51)
+                        v["lane_occupancy"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
+                    v["kernel"] = k
+                    entry[key + "_valu"] = v
+        latest["workloads"][wl] = entry
+        print("wrote %s_pmc_%s.json:" % (tag, wl), {k: v for k, v in entry.items() if k.endswith("per_launch")})
+    if latest["workloads"]:
+        json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+        print("wrote pmc_latest.json")
 
 
 if __name__ == "__main__":
