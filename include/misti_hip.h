@@ -193,7 +193,8 @@ int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
  * config 3 runs it from 16 384 random starts.  Every start follows scipy.optimize.minimize(method='Nelder-Mead')
  * decision for decision (same simplex, same evaluation count), so its result equals SciPy's on the same objective.
  * Simplices, function values and decisions stay in HBM; per iteration the reflection points of all starts are one
- * engine batch, their expansion / contraction points a second, shrunk vertices a third; finished starts cost nothing.
+ * engine batch, their expansion / contraction points a second, shrunk vertices a third; finished starts cost nothing;
+ * once few starts are left, iterations become speculative (misti_nm_last_spec_iterations).
  * Host buffers; synchronous.
  *   starts      [n_start][n_param]   (n_param >= 1)
  *   split_time  the split time of every evaluation (fractional allowed)
@@ -207,10 +208,34 @@ int misti_nm_solve(misti_ctx* ctx, int64_t n_start, const double* starts, double
                    double xatol, double fatol, int32_t maxiter,
                    double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status);
 
+/* Batched basin hopping: scipy.optimize.basinhopping(func, x0, niter, T, stepsize, minimizer_kwargs=dict(method='Nelder-Mead'),
+ * interval, target_accept_rate, stepwise_factor, rng=...) for n_start starts at once - the reference's global search,
+ * MigrationInference.Solve(globalOpt=True) (MigrationInference.py:723-725: T = 0.5, Nelder-Mead with SciPy's defaults, i.e.
+ * xatol = fatol = 1e-4, maxiter = maxfev = 200 x n_param), which BASELINE config 3 runs from 16 384 random starts.
+ * Every start follows SciPy's runner step for step (_basinhopping.py: initial minimisation, then per hop
+ * AdaptiveStepsize.take_step, RandomDisplacement, the local minimisation - misti_nm_solve's machinery, all starts in one set of
+ * engine batches - Metropolis.accept_reject, Storage.update).  Incumbents, step sizes and decisions stay in HBM.
+ * The random numbers are the CALLER's: SciPy draws, per hop, n_param uniforms for the displacement and then one for the
+ * acceptance test from one generator; their number does not depend on the data, so the caller draws them up front -
+ *   uniforms   [n_start][niter][n_param + 1]   numpy.random.Generator.random() values (in [0, 1)) in exactly that order,
+ *                                              start s from the generator SciPy would be given for start s -
+ * and start s then reproduces scipy.optimize.basinhopping(rng = that generator) on the same objective (x, fun, nfev,
+ * minimization_failures).  Host buffers; synchronous.
+ *   x, llh     [n_start][n_param], [n_start]   lowest successful minimum found (res.x, -res.fun)
+ *   nfev, failures, accepted [n_start] or NULL  res.nfev, res.minimization_failures, hops accepted */
+int misti_basinhopping(misti_ctx* ctx, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                       int32_t niter, double T, double stepsize, int32_t interval, double target_accept_rate, double stepwise_factor,
+                       double xatol, double fatol, int32_t nm_maxiter, int64_t nm_maxfev, const double* uniforms,
+                       double* x, double* llh, int32_t* nfev, int32_t* failures, int32_t* accepted);
+
 /* Work counters of the last misti_nm_solve on this context: [0] iterations issued, [1] batch slots over all iterations
  * (live starts plus the slack of the two-iterations-old count that sizes the batches; x (2 + n_param) = candidates
  * handed to the engine after the initial simplices). */
 int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
+/* ... and how many of those iterations were SPECULATIVE: with few starts still running (at most 1 024 / (4 + n_param)) all
+ * 4 + n_param points SciPy could ask for in an iteration go out as one engine batch and one kernel takes its decisions
+ * from the values it would have asked for - one chain latency per iteration instead of three; nfev stays SciPy's count. */
+int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
 
 /* ---- solver trace (parity diagnostics) ---------------------------------------- */
 /* The reference's corrected rates are DEFINED by where SciPy's trust-region iteration stops

@@ -64,6 +64,10 @@ SYMBOLS = {
     "misti_nm_solve": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_nm_last_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "misti_nm_last_spec_iterations": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "misti_basinhopping": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_enable_solver_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_last_solver_trace": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "misti_llk_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -110,6 +110,7 @@ struct misti_ctx {
     int32_t* nm_live_host = nullptr;    // pinned: live starts after the last two finished iterations
     int64_t nm_iterations = 0;          // iterations issued by the last misti_nm_solve
     int64_t nm_slots = 0;               // and the batch slots they had in total (live starts + the stale-count slack)
+    int64_t nm_spec_iterations = 0;     // how many of those iterations were speculative (all points of a start in one batch)
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double ms[3] = {0, 0, 0};
@@ -724,24 +725,40 @@ int misti_forward_rates(misti_ctx* c, int64_t n_cand, const double* split, const
     return 0;
 }
 
-int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
-                   double xatol, double fatol, int32_t maxiter,
-                   double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status) {
-    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
-    if (n_start < 0) return fail(MISTI_E_ARG, "negative number of starts");
-    if (n_start == 0) return 0;
+}  // extern "C"
+
+namespace {
+
+// Device-resident state of one batched Nelder-Mead run, carved from the context's nm buffers.
+struct NmWork {
+    misti::NmState st{};
+    double *llk0 = nullptr, *llk1 = nullptr, *llk2 = nullptr, *llk3 = nullptr, *llk_spec = nullptr;
+    double *d_starts = nullptr;      // [S][N] in: start points; out: best vertices
+    double *d_llh = nullptr;         // [S]    out: their log-likelihood
+    double *d_row = nullptr;         // [8]    the data JSFS
+    double *extra_f64 = nullptr;     // whatever the caller asked for beyond the minimiser's own state
+    int32_t *idx[2] = {nullptr, nullptr}, *cnt = nullptr, *extra_i32 = nullptr;
+};
+
+// Live starts up to which an iteration is speculative (misti_nm.hip): all 4 + N points of a start in one batch, as long as the
+// batch still runs one chain per wave (FOLLOW_MAX_CHAINS candidates, each its own chain) - there the iteration costs one
+// chain latency instead of three.  MISTI_NM_SPEC=0 turns it off (tests compare the two paths).
+int64_t nm_spec_cap(int N) {
+    const char* e = getenv("MISTI_NM_SPEC");
+    if (e && e[0] == '0') return 0;
+    return misti::FOLLOW_MAX_CHAINS / (4 + N);
+}
+
+int nm_prepare(misti_ctx* c, int64_t n_start, NmWork& w, size_t extra_f64 = 0, size_t extra_i32 = 0) {
     const int N = c->dm.n_param;
-    if (N < 1) return fail(MISTI_E_ARG, "the model has no optimised parameter");
-    if (!starts || !jsfs_row || !x || !llh) return fail(MISTI_E_ARG, "starts / jsfs_row / x / llh is NULL");
-    if (maxiter < 1) return fail(MISTI_E_ARG, "maxiter must be >= 1");
-    if (n_start > INT32_MAX / (8 * (N + 1))) return fail(MISTI_E_LIMIT, "too many starts for one call");
-    HIP_TRY(hipSetDevice(c->device));
     const size_t S = (size_t)n_start, V = (size_t)N + 1;
+    const size_t cap = (size_t)nm_spec_cap(N), K = 4 + (size_t)N;
     // one allocation per type: simplices and points | counters and slot tables
     const size_t f64_n = S * V * N * 2 + S * V + S * N * 2 + S * N * N + S + S * V + 2 * S + S * N      // state + split arrays
                          + S * V + 2 * S + S * N                                                           // llk of the four batches
-                         + S * N + S + 8;                                                                   // inputs / outputs, jsfs row
-    const size_t i32_n = 7 * S + 4;
+                         + S * N + S + 8                                                                   // inputs / outputs, jsfs row
+                         + cap * K * (N + 2) + extra_f64;                                                  // speculative points, their splits and values
+    const size_t i32_n = 7 * S + 4 + extra_i32;
     HIP_TRY(c->nm_f64.reserve(f64_n * sizeof(double)));
     HIP_TRY(c->nm_i32.reserve(i32_n * sizeof(int32_t)));
     if (!c->nm_live_host) {
@@ -751,33 +768,47 @@ int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double s
             return fail(MISTI_E_HIP, "pinned allocation for the live-start count failed");
         }
     }
-    misti::NmState st{};
-    st.S = n_start; st.N = N; st.maxiter = maxiter; st.maxfun = INT64_MAX; st.xatol = xatol; st.fatol = fatol; st.split = split_time;
+    misti::NmState& st = w.st;
+    st.S = n_start; st.N = N;
     double* d = c->nm_f64.as<double>();
     st.sim = d; d += S * V * N; st.scratch = d; d += S * V * N; st.fsim = d; d += S * V;
     st.p1 = d; d += S * N; st.p2 = d; d += S * N; st.p3 = d; d += S * N * N; st.fxr = d; d += S;
     st.split0 = d; d += S * V; st.split1 = d; d += S; st.split2 = d; d += S; st.split3 = d; d += S * N;
-    double* llk0 = d; d += S * V;
-    double* llk1 = d; d += S;
-    double* llk2 = d; d += S;
-    double* llk3 = d; d += S * N;
-    double* d_starts = d; d += S * N;        // reused for the best vertices at the end
-    double* d_llh = d; d += S;
-    double* d_row = d;
+    w.llk0 = d; d += S * V;
+    w.llk1 = d; d += S;
+    w.llk2 = d; d += S;
+    w.llk3 = d; d += S * N;
+    w.d_starts = d; d += S * N;
+    w.d_llh = d; d += S;
+    w.d_row = d; d += 8;
+    st.ps = d; d += cap * K * N; st.ps_split = d; d += cap * K; w.llk_spec = d; d += cap * K;
+    st.spec_cap = (int64_t)cap;
+    w.extra_f64 = d;
     int32_t* q = c->nm_i32.as<int32_t>();
     st.nit = q; q += S; st.nfev = q; q += S; st.done = q; q += S; st.kind = q; q += S; st.shrunk = q; q += S;
-    int32_t* idx[2] = {q, q + S}; q += 2 * S;
-    int32_t* cnt = q;                        // [2] live starts of the iteration in progress / of the next one
+    w.idx[0] = q; w.idx[1] = q + S; q += 2 * S;
+    w.cnt = q; q += 4;                       // [2] live starts of the iteration in progress / of the next one
+    w.extra_i32 = q;
+    return 0;
+}
+
+// One minimisation of every start from w.d_starts (device); leaves best vertices in w.d_starts, their log-likelihood in w.d_llh,
+// SciPy's counters in st.nit / st.nfev and the termination status in st.shrunk (0 converged, 1 evaluation budget, 2 iteration
+// budget).  Asynchronous except for the 4-byte live counts; results are complete when the stream is.
+int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fatol, int32_t maxiter, int64_t maxfun) {
+    misti::NmState& st = w.st;
+    const int N = st.N;
+    const size_t S = (size_t)st.S, V = (size_t)N + 1;
+    st.maxiter = maxiter; st.maxfun = maxfun; st.xatol = xatol; st.fatol = fatol; st.split = split_time;
     hipStream_t sm = c->stream;
-    HIP_TRY(hipMemcpyAsync(d_starts, starts, S * N * sizeof(double), hipMemcpyHostToDevice, sm));
-    HIP_TRY(hipMemcpyAsync(d_row, jsfs_row, 8 * sizeof(double), hipMemcpyHostToDevice, sm));
+    int32_t* cnt = w.cnt;
     HIP_TRY(hipMemsetAsync(cnt, 0, 4 * sizeof(int32_t), sm));
     HIP_TRY(hipMemsetAsync(st.split1, 0xBF, S * sizeof(double), sm));          // all-0xBF bytes: a negative double = "no point in this slot"
-    HIP_TRY(misti::launch_nm_init(st, d_starts, sm));
-    if (int r = run_dev(c, (int64_t)(S * V), st.split0, st.sim, nullptr, 1, d_row, llk0, nullptr, nullptr, nullptr, nullptr)) return r;
+    HIP_TRY(misti::launch_nm_init(st, w.d_starts, sm));
+    if (int r = run_dev(c, (int64_t)(S * V), st.split0, st.sim, nullptr, 1, w.d_row, w.llk0, nullptr, nullptr, nullptr, nullptr)) return r;
     int cur = 0;
-    st.idx_next = idx[cur]; st.count_next = cnt + cur;
-    HIP_TRY(misti::launch_nm_begin(st, llk0, sm));
+    st.idx_next = w.idx[cur]; st.count_next = cnt + cur;
+    HIP_TRY(misti::launch_nm_begin(st, w.llk0, sm));
     // The host runs at most two iterations ahead of the device: before issuing iteration k it waits for the event of
     // iteration k - 2 and reads the count of live starts that iteration left in pinned memory (4 bytes; nothing else of
     // the search leaves the device).  That count bounds the live starts of iteration k from above - the number only falls -
@@ -791,7 +822,8 @@ int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double s
     HIP_TRY(hipEventRecord(ev[0], sm));
     HIP_TRY(hipEventSynchronize(ev[0]));
     int64_t bound = live_host[0];
-    int64_t issued = 0, slots = 0;
+    int64_t issued = 0, slots = 0, spec_iters = 0;
+    const int64_t K = 4 + N;
     for (int it = 0; bound > 0 && it < maxiter; ++it) {
         const int slot = it & 1;
         if (it >= 2) {
@@ -799,31 +831,125 @@ int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double s
             if (live_host[slot] < bound) bound = live_host[slot];
             if (bound <= 0) break;
         }
-        st.idx_cur = idx[cur]; st.count_cur = cnt + cur;
-        st.idx_next = idx[cur ^ 1]; st.count_next = cnt + (cur ^ 1);
-        if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, d_row, llk1, nullptr, nullptr, nullptr, nullptr)) return r;
-        HIP_TRY(misti::launch_nm_reflect(st, bound, llk1, sm));
-        if (int r = run_dev(c, bound, st.split2, st.p2, nullptr, 1, d_row, llk2, nullptr, nullptr, nullptr, nullptr)) return r;
-        HIP_TRY(misti::launch_nm_accept(st, bound, llk2, sm));
-        if (int r = run_dev(c, bound * N, st.split3, st.p3, nullptr, 1, d_row, llk3, nullptr, nullptr, nullptr, nullptr)) return r;
-        HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
-        HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
-        HIP_TRY(misti::launch_nm_finish(st, bound, llk3, sm));
+        st.idx_cur = w.idx[cur]; st.count_cur = cnt + cur;
+        st.idx_next = w.idx[cur ^ 1]; st.count_next = cnt + (cur ^ 1);
+        if (bound <= st.spec_cap) {
+            // speculative iteration: every point SciPy could ask for, one batch, one decision kernel
+            HIP_TRY(misti::launch_nm_spec_points(st, bound, sm));
+            if (int r = run_dev(c, bound * K, st.ps_split, st.ps, nullptr, 1, w.d_row, w.llk_spec, nullptr, nullptr, nullptr, nullptr)) return r;
+            HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
+            HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
+            HIP_TRY(misti::launch_nm_spec_finish(st, bound, w.llk_spec, sm));
+            ++spec_iters;
+        } else {
+            if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, w.d_row, w.llk1, nullptr, nullptr, nullptr, nullptr)) return r;
+            HIP_TRY(misti::launch_nm_reflect(st, bound, w.llk1, sm));
+            if (int r = run_dev(c, bound, st.split2, st.p2, nullptr, 1, w.d_row, w.llk2, nullptr, nullptr, nullptr, nullptr)) return r;
+            HIP_TRY(misti::launch_nm_accept(st, bound, w.llk2, sm));
+            if (int r = run_dev(c, bound * N, st.split3, st.p3, nullptr, 1, w.d_row, w.llk3, nullptr, nullptr, nullptr, nullptr)) return r;
+            HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
+            HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
+            HIP_TRY(misti::launch_nm_finish(st, bound, w.llk3, sm));
+        }
         HIP_TRY(hipMemcpyAsync((void*)&live_host[slot], cnt + (cur ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost, sm));
         HIP_TRY(hipEventRecord(ev[slot], sm));
         cur ^= 1;
         ++issued;
         slots += bound;
     }
-    c->nm_iterations = issued;
-    c->nm_slots = slots;
+    c->nm_iterations += issued;
+    c->nm_slots += slots;
+    c->nm_spec_iterations += spec_iters;
     // results (device buffers reused: best vertices over the starts)
-    HIP_TRY(misti::launch_nm_result(st, d_starts, d_llh, st.shrunk, sm));
-    HIP_TRY(hipMemcpyAsync(x, d_starts, S * N * sizeof(double), hipMemcpyDeviceToHost, sm));
-    HIP_TRY(hipMemcpyAsync(llh, d_llh, S * sizeof(double), hipMemcpyDeviceToHost, sm));
-    if (nit) HIP_TRY(hipMemcpyAsync(nit, st.nit, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
-    if (nfev) HIP_TRY(hipMemcpyAsync(nfev, st.nfev, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
-    if (status) HIP_TRY(hipMemcpyAsync(status, st.shrunk, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(misti::launch_nm_result(st, w.d_starts, w.d_llh, st.shrunk, sm));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int misti_nm_solve(misti_ctx* c, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                   double xatol, double fatol, int32_t maxiter,
+                   double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_start < 0) return fail(MISTI_E_ARG, "negative number of starts");
+    if (n_start == 0) return 0;
+    const int N = c->dm.n_param;
+    if (N < 1) return fail(MISTI_E_ARG, "the model has no optimised parameter");
+    if (!starts || !jsfs_row || !x || !llh) return fail(MISTI_E_ARG, "starts / jsfs_row / x / llh is NULL");
+    if (maxiter < 1) return fail(MISTI_E_ARG, "maxiter must be >= 1");
+    if (n_start > INT32_MAX / (8 * (N + 1))) return fail(MISTI_E_LIMIT, "too many starts for one call");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t S = (size_t)n_start;
+    NmWork w;
+    if (int r = nm_prepare(c, n_start, w)) return r;
+    hipStream_t sm = c->stream;
+    HIP_TRY(hipMemcpyAsync(w.d_starts, starts, S * N * sizeof(double), hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(w.d_row, jsfs_row, 8 * sizeof(double), hipMemcpyHostToDevice, sm));
+    c->nm_iterations = c->nm_slots = c->nm_spec_iterations = 0;
+    if (int r = nm_run(c, w, split_time, xatol, fatol, maxiter, INT64_MAX)) return r;
+    HIP_TRY(hipMemcpyAsync(x, w.d_starts, S * N * sizeof(double), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipMemcpyAsync(llh, w.d_llh, S * sizeof(double), hipMemcpyDeviceToHost, sm));
+    if (nit) HIP_TRY(hipMemcpyAsync(nit, w.st.nit, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (nfev) HIP_TRY(hipMemcpyAsync(nfev, w.st.nfev, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (status) HIP_TRY(hipMemcpyAsync(status, w.st.shrunk, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipStreamSynchronize(sm));
+    return 0;
+}
+
+int misti_basinhopping(misti_ctx* c, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                       int32_t niter, double T, double stepsize, int32_t interval, double target_accept_rate, double stepwise_factor,
+                       double xatol, double fatol, int32_t nm_maxiter, int64_t nm_maxfev, const double* uniforms,
+                       double* x, double* llh, int32_t* nfev, int32_t* failures, int32_t* accepted) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (n_start < 0 || niter < 0) return fail(MISTI_E_ARG, "negative number of starts / hops");
+    if (n_start == 0) return 0;
+    const int N = c->dm.n_param;
+    if (N < 1) return fail(MISTI_E_ARG, "the model has no optimised parameter");
+    if (!starts || !jsfs_row || !x || !llh || (niter > 0 && !uniforms)) return fail(MISTI_E_ARG, "starts / jsfs_row / uniforms / x / llh is NULL");
+    if (nm_maxiter < 1 || nm_maxfev < 1 || interval < 1) return fail(MISTI_E_ARG, "nm_maxiter, nm_maxfev and interval must be >= 1");
+    if (n_start > INT32_MAX / (8 * (N + 1))) return fail(MISTI_E_LIMIT, "too many starts for one call");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t S = (size_t)n_start, U = S * (size_t)niter * (size_t)(N + 1);
+    NmWork w;
+    if (int r = nm_prepare(c, n_start, w, S * N * 3 + S * 3 + U, 7 * S)) return r;
+    misti::BhState bh{};
+    bh.S = n_start; bh.N = N;
+    bh.beta = T != 0.0 ? 1.0 / T : INFINITY;
+    bh.target = target_accept_rate; bh.factor = stepwise_factor; bh.interval = interval;
+    double* d = w.extra_f64;
+    bh.x_cur = d; d += S * N; bh.x_best = d; d += S * N;
+    double* d_trial = d; d += S * N;
+    bh.f_cur = d; d += S; bh.f_best = d; d += S; bh.stepsize = d; d += S;
+    double* d_uni = d;
+    int32_t* q = w.extra_i32;
+    bh.ok_cur = q; q += S; bh.ok_best = q; q += S; bh.nstep = q; q += S; bh.naccept = q; q += S; bh.nfev = q; q += S; bh.failures = q; q += S; bh.accepted = q;
+    hipStream_t sm = c->stream;
+    HIP_TRY(hipMemcpyAsync(w.d_starts, starts, S * N * sizeof(double), hipMemcpyHostToDevice, sm));
+    HIP_TRY(hipMemcpyAsync(w.d_row, jsfs_row, 8 * sizeof(double), hipMemcpyHostToDevice, sm));
+    if (U) HIP_TRY(hipMemcpyAsync(d_uni, uniforms, U * sizeof(double), hipMemcpyHostToDevice, sm));
+    {
+        std::vector<double> st0(S, stepsize);
+        HIP_TRY(hipMemcpyAsync(bh.stepsize, st0.data(), S * sizeof(double), hipMemcpyHostToDevice, sm));
+        HIP_TRY(hipStreamSynchronize(sm));                  // st0 is a local
+    }
+    c->nm_iterations = c->nm_slots = c->nm_spec_iterations = 0;
+    // BasinHoppingRunner.__init__: the initial minimisation from the start itself
+    if (int r = nm_run(c, w, split_time, xatol, fatol, nm_maxiter, nm_maxfev)) return r;
+    HIP_TRY(misti::launch_bh_update(bh, w.st, w.d_starts, w.d_llh, w.st.shrunk, -1, niter, d_uni, sm));
+    for (int hop = 0; hop < niter; ++hop) {                 // one_cycle, all starts in step
+        HIP_TRY(misti::launch_bh_step(bh, hop, niter, d_uni, d_trial, sm));
+        HIP_TRY(hipMemcpyAsync(w.d_starts, d_trial, S * N * sizeof(double), hipMemcpyDeviceToDevice, sm));
+        if (int r = nm_run(c, w, split_time, xatol, fatol, nm_maxiter, nm_maxfev)) return r;
+        HIP_TRY(misti::launch_bh_update(bh, w.st, w.d_starts, w.d_llh, w.st.shrunk, hop, niter, d_uni, sm));
+    }
+    HIP_TRY(misti::launch_bh_result(bh, w.d_starts, w.d_llh, sm));
+    HIP_TRY(hipMemcpyAsync(x, w.d_starts, S * N * sizeof(double), hipMemcpyDeviceToHost, sm));
+    HIP_TRY(hipMemcpyAsync(llh, w.d_llh, S * sizeof(double), hipMemcpyDeviceToHost, sm));
+    if (nfev) HIP_TRY(hipMemcpyAsync(nfev, bh.nfev, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (failures) HIP_TRY(hipMemcpyAsync(failures, bh.failures, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+    if (accepted) HIP_TRY(hipMemcpyAsync(accepted, bh.accepted, S * sizeof(int32_t), hipMemcpyDeviceToHost, sm));
     HIP_TRY(hipStreamSynchronize(sm));
     return 0;
 }
@@ -832,6 +958,12 @@ int misti_nm_last_stats(misti_ctx* c, int64_t stats[2]) {
     if (!c || !stats) return fail(MISTI_E_ARG, "ctx / output is NULL");
     stats[0] = c->nm_iterations;
     stats[1] = c->nm_slots;
+    return 0;
+}
+
+int misti_nm_last_spec_iterations(misti_ctx* c, int64_t* n) {
+    if (!c || !n) return fail(MISTI_E_ARG, "ctx / output is NULL");
+    *n = c->nm_spec_iterations;
     return 0;
 }
 

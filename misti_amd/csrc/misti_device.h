@@ -123,6 +123,10 @@ struct NmState {
     double* split1;         // [S]       ... of the reflection batch (negative: no point in this slot)
     double* split2;         // [S]
     double* split3;         // [S * N]
+    // speculative iterations (few live starts: latency-bound): every point SciPy COULD ask for in the iteration, one batch
+    double* ps;             // [spec_cap][4 + N][N]  reflection, expansion, outside / inside contraction, the N shrunk vertices
+    double* ps_split;       // [spec_cap * (4 + N)]
+    int64_t spec_cap;       // live starts up to which an iteration is speculative
     const int32_t* idx_cur; // [S] slot -> start of the iteration in progress
     const int32_t* count_cur;   // [1] its number of live starts
     int32_t* idx_next;      // [S] slot -> start of the next iteration (filled by the kernel that ends this one)
@@ -134,6 +138,36 @@ hipError_t launch_nm_reflect(const NmState& st, int64_t bound, const double* llk
 hipError_t launch_nm_accept(const NmState& st, int64_t bound, const double* llk2, hipStream_t stream);
 hipError_t launch_nm_finish(const NmState& st, int64_t bound, const double* llk3, hipStream_t stream);
 hipError_t launch_nm_result(const NmState& st, double* x, double* llh, int32_t* status, hipStream_t stream);
+hipError_t launch_nm_spec_points(const NmState& st, int64_t bound, hipStream_t stream);
+hipError_t launch_nm_spec_finish(const NmState& st, int64_t bound, const double* llk, hipStream_t stream);
+
+// Batched basin hopping (scipy.optimize.basinhopping with Nelder-Mead as the local minimiser; reference semantics
+// MigrationInference.Solve(globalOpt=True), /root/reference/MigrationInference.py:723-725): everything a start owns besides its simplex.
+struct BhState {
+    int64_t S;
+    int N;
+    double beta;            // 1 / T (inf for T == 0), Metropolis
+    double target, factor;  // AdaptiveStepsize: target acceptance rate, stepwise factor
+    int interval;
+    double* x_cur;          // [S][N] incumbent
+    double* f_cur;          // [S]
+    int32_t* ok_cur;        // [S]    success of the incumbent's minimisation
+    double* x_best;         // [S][N] Storage: lowest successful result
+    double* f_best;         // [S]
+    int32_t* ok_best;       // [S]
+    double* stepsize;       // [S]
+    int32_t* nstep;         // [S]    AdaptiveStepsize.nstep (reset at every adjustment)
+    int32_t* naccept;       // [S]
+    int32_t* nfev;          // [S]    res.nfev: evaluations of all minimisations
+    int32_t* failures;      // [S]    res.minimization_failures
+    int32_t* accepted;      // [S]    hops accepted (not a SciPy field; diagnostics)
+};
+// after a minimisation from `trial` (results in x_min / llh_min / nm.nfev / nm status): initial one (hop < 0) or hop `hop` with its Metropolis draw
+hipError_t launch_bh_update(const BhState& bh, const NmState& nm, const double* x_min, const double* llh_min, const int32_t* nm_status,
+                            int hop, int niter, const double* uniforms, hipStream_t stream);
+// next trial points: AdaptiveStepsize.take_step + RandomDisplacement with the pre-drawn uniforms of hop `hop`
+hipError_t launch_bh_step(const BhState& bh, int hop, int niter, const double* uniforms, double* trial, hipStream_t stream);
+hipError_t launch_bh_result(const BhState& bh, double* x, double* llh, hipStream_t stream);
 
 // Replicate epilogue fused into the spectrum kernel up to this many replicates (one launch less per batch).
 constexpr int LLK_INLINE_MAX = 8;

@@ -222,6 +222,147 @@ void nm_finish_kernel(NmState st, int64_t bound, const double* __restrict__ llk3
     next_reflection(st, s);
 }
 
+// ---- speculative iteration (few live starts) ---------------------------------------------------------------------------------
+// With a handful of starts still running an iteration is three dependent engine batches of a few candidates each - three
+// times the latency of one lambda-correction chain while the chip idles (BASELINE config 3: 64 of 16 384 starts never meet
+// fatol and run to maxiter; that tail was 70 % of the search's wall time).  Every point SciPy COULD evaluate in an iteration is
+// known at its top - reflection, expansion, outside and inside contraction, the N shrunk vertices - so below spec_cap live
+// starts all 4 + N of them go out as ONE batch and one kernel takes SciPy's decisions from the values it would have asked
+// for, counting only those (nfev is SciPy's).  Same expressions as the three-batch path: same bits.
+__global__ __launch_bounds__(256)
+void nm_spec_points_kernel(NmState st, int64_t bound) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bound) return;
+    const int N = st.N, V = N + 1, K = 4 + N;
+    double* pt = st.ps + i * (int64_t)K * N;
+    double* sp = st.ps_split + i * K;
+    if (i >= st.count_cur[0]) { for (int j = 0; j < K; ++j) { sp[j] = -1.0; for (int k = 0; k < N; ++k) pt[j * N + k] = 0.0; } return; }
+    const int64_t s = st.idx_cur[i];
+    const double* x = st.sim + s * (int64_t)V * N;
+    const double* p1 = st.p1 + i * N;
+    for (int k = 0; k < N; ++k) {
+        const double xb = centroid(x, N, k), w = x[N * N + k];
+        pt[0 * N + k] = p1[k];                                                            // xr (next_reflection)
+        pt[1 * N + k] = lin2(1.0 + NM_RHO * NM_CHI, xb, NM_RHO * NM_CHI, w);              // xe
+        pt[2 * N + k] = lin2(1.0 + NM_PSI * NM_RHO, xb, NM_PSI * NM_RHO, w);              // xc
+        pt[3 * N + k] = rn((1.0 - NM_PSI) * xb) + rn(NM_PSI * w);                         // xcc
+        for (int j = 1; j < V; ++j) pt[(3 + j) * N + k] = x[k] + rn(NM_SIGMA * rn(x[j * N + k] - x[k]));   // shrunk vertex j
+    }
+    for (int j = 0; j < K; ++j) sp[j] = st.split;
+}
+
+__global__ __launch_bounds__(256)
+void nm_spec_finish_kernel(NmState st, int64_t bound, const double* __restrict__ llk) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bound || i >= st.count_cur[0]) return;
+    const int N = st.N, V = N + 1, K = 4 + N;
+    const int64_t s = st.idx_cur[i];
+    double* f = st.fsim + s * V;
+    double* x = st.sim + s * (int64_t)V * N;
+    const double* pt = st.ps + i * (int64_t)K * N;
+    const double* v = llk + i * K;
+    const double fxr = objective(v[0]);
+    int nfev = st.nfev[s] + 1;
+    int take = 0;                 // which point replaces the worst vertex; -1: shrink
+    double ftake = fxr;
+    if (fxr < f[0]) {             // expansion
+        const double f2 = objective(v[1]); ++nfev;
+        if (f2 < fxr) { take = 1; ftake = f2; }
+    } else if (fxr < f[N - 1]) {
+        // accepted as it is
+    } else if (fxr < f[N]) {      // outside contraction
+        const double f2 = objective(v[2]); ++nfev;
+        if (f2 <= fxr) { take = 2; ftake = f2; } else take = -1;
+    } else {                      // inside contraction
+        const double f2 = objective(v[3]); ++nfev;
+        if (f2 < f[N]) { take = 3; ftake = f2; } else take = -1;
+    }
+    if (take >= 0) { for (int k = 0; k < N; ++k) x[N * N + k] = pt[take * N + k]; f[N] = ftake; }
+    else {
+        for (int j = 1; j < V; ++j) { for (int k = 0; k < N; ++k) x[j * N + k] = pt[(3 + j) * N + k]; f[j] = objective(v[3 + j]); }
+        nfev += N;
+    }
+    st.nfev[s] = nfev;
+    st.shrunk[s] = take < 0 ? 1 : 0;
+    st.nit[s] += 1;
+    sort_simplex(st, s);
+    next_reflection(st, s);
+}
+
+// ---- basin hopping around the batched minimiser ---------------------------------------------------------------------------
+// scipy.optimize.basinhopping (SciPy 1.15.3, _basinhopping.py) per start: BasinHoppingRunner.__init__ / one_cycle,
+// AdaptiveStepsize.take_step (:245-250, adjustment every `interval` steps :230-243), RandomDisplacement (:275-278:
+// x += rng.uniform(-stepsize, stepsize)), Metropolis.accept_reject (:316-336), Storage.update (:29-35).  The uniforms are
+// drawn on the host by the caller's own numpy Generator, in SciPy's order (N for the displacement, then 1 for the acceptance
+// test, per hop) - their NUMBER does not depend on the data, only their use does - so a start reproduces
+// scipy.optimize.basinhopping(rng=that generator) on the same objective.
+__global__ __launch_bounds__(256)
+void bh_update_kernel(BhState bh, NmState nm, const double* __restrict__ x_min, const double* __restrict__ llh_min, const int32_t* __restrict__ nm_status,
+                      int hop, int niter, const double* __restrict__ uniforms) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bh.S) return;
+    const int N = bh.N;
+    const double f_new = -llh_min[s];                       // OptimizeResult.fun of the minimisation (+inf: no vertex has a value)
+    const bool ok_new = nm_status[s] == 0;
+    if (hop < 0) {                                          // BasinHoppingRunner.__init__ (:80-97)
+        for (int k = 0; k < N; ++k) { bh.x_cur[s * N + k] = x_min[s * N + k]; bh.x_best[s * N + k] = x_min[s * N + k]; }
+        bh.f_cur[s] = f_new; bh.f_best[s] = f_new;
+        bh.ok_cur[s] = ok_new; bh.ok_best[s] = ok_new;
+        bh.nfev[s] = nm.nfev[s];
+        bh.failures[s] = ok_new ? 0 : 1;
+        bh.accepted[s] = 0;
+        bh.nstep[s] = 0; bh.naccept[s] = 0;
+        return;
+    }
+    bh.nfev[s] += nm.nfev[s];
+    if (!ok_new) bh.failures[s] += 1;
+    // Metropolis: prod = -(f_new - f_old) * beta; w = exp(min(0, prod)) - Python's min(0, nan) is 0
+    const double prod = -(f_new - bh.f_cur[s]) * bh.beta;
+    const double w = exp(prod < 0.0 ? prod : 0.0);
+    const double rnd = uniforms[(s * (int64_t)niter + hop) * (N + 1) + N];
+    const bool accept = (w >= rnd) && (ok_new || !bh.ok_cur[s]);
+    if (accept) {
+        bh.naccept[s] += 1;                                 // AdaptiveStepsize.report
+        bh.accepted[s] += 1;
+        for (int k = 0; k < N; ++k) bh.x_cur[s * N + k] = x_min[s * N + k];
+        bh.f_cur[s] = f_new;
+        bh.ok_cur[s] = ok_new;
+        if (ok_new && (f_new < bh.f_best[s] || !bh.ok_best[s])) {     // Storage.update
+            for (int k = 0; k < N; ++k) bh.x_best[s * N + k] = x_min[s * N + k];
+            bh.f_best[s] = f_new;
+            bh.ok_best[s] = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void bh_step_kernel(BhState bh, int hop, int niter, const double* __restrict__ uniforms, double* __restrict__ trial) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bh.S) return;
+    const int N = bh.N;
+    int nstep = bh.nstep[s] + 1;
+    double step = bh.stepsize[s];
+    if (nstep % bh.interval == 0) {                         // _adjust_step_size
+        const double rate = (double)bh.naccept[s] / (double)nstep;
+        step = rate > bh.target ? step / bh.factor : step * bh.factor;
+        bh.stepsize[s] = step;
+        bh.naccept[s] = 0;
+        nstep = 0;
+    }
+    bh.nstep[s] = nstep;
+    const double lo = -step, range = step - lo;             // Generator.uniform(low, high): low + (high - low) * next_double
+    const double* u = uniforms + (s * (int64_t)niter + hop) * (N + 1);
+    for (int k = 0; k < N; ++k) trial[s * N + k] = bh.x_cur[s * N + k] + (lo + rn(range * u[k]));
+}
+
+__global__ __launch_bounds__(256)
+void bh_result_kernel(BhState bh, double* __restrict__ x, double* __restrict__ llh) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= bh.S) return;
+    for (int k = 0; k < bh.N; ++k) x[s * bh.N + k] = bh.x_best[s * bh.N + k];
+    llh[s] = -bh.f_best[s];
+}
+
 // results: best vertex, its value (as a log-likelihood), counters
 __global__ __launch_bounds__(256)
 void nm_result_kernel(NmState st, double* __restrict__ x_out, double* __restrict__ llh_out, int32_t* __restrict__ status) {
@@ -257,6 +398,27 @@ hipError_t launch_nm_finish(const NmState& st, int64_t bound, const double* llk3
 }
 hipError_t launch_nm_result(const NmState& st, double* x, double* llh, int32_t* status, hipStream_t stream) {
     hipLaunchKernelGGL(nm_result_kernel, nm_grid(st.S), dim3(256), 0, stream, st, x, llh, status);
+    return hipGetLastError();
+}
+hipError_t launch_nm_spec_points(const NmState& st, int64_t bound, hipStream_t stream) {
+    hipLaunchKernelGGL(nm_spec_points_kernel, nm_grid(bound), dim3(256), 0, stream, st, bound);
+    return hipGetLastError();
+}
+hipError_t launch_nm_spec_finish(const NmState& st, int64_t bound, const double* llk, hipStream_t stream) {
+    hipLaunchKernelGGL(nm_spec_finish_kernel, nm_grid(bound), dim3(256), 0, stream, st, bound, llk);
+    return hipGetLastError();
+}
+hipError_t launch_bh_update(const BhState& bh, const NmState& nm, const double* x_min, const double* llh_min, const int32_t* nm_status,
+                            int hop, int niter, const double* uniforms, hipStream_t stream) {
+    hipLaunchKernelGGL(bh_update_kernel, nm_grid(bh.S), dim3(256), 0, stream, bh, nm, x_min, llh_min, nm_status, hop, niter, uniforms);
+    return hipGetLastError();
+}
+hipError_t launch_bh_step(const BhState& bh, int hop, int niter, const double* uniforms, double* trial, hipStream_t stream) {
+    hipLaunchKernelGGL(bh_step_kernel, nm_grid(bh.S), dim3(256), 0, stream, bh, hop, niter, uniforms, trial);
+    return hipGetLastError();
+}
+hipError_t launch_bh_result(const BhState& bh, double* x, double* llh, hipStream_t stream) {
+    hipLaunchKernelGGL(bh_result_kernel, nm_grid(bh.S), dim3(256), 0, stream, bh, x, llh);
     return hipGetLastError();
 }
 

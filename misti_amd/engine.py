@@ -222,7 +222,41 @@ class Engine:
                                             ptr(x), ptr(llh), ptr(nit), ptr(nfev), ptr(status)))
         stats = (C.c_int64 * 2)()
         _lib.check(self._lib.misti_nm_last_stats(self._ctx, stats))
-        return dict(x=x, llh=llh, nit=nit, nfev=nfev, status=status, iterations_issued=int(stats[0]), slots=int(stats[1]))
+        spec = C.c_int64(0)
+        _lib.check(self._lib.misti_nm_last_spec_iterations(self._ctx, C.byref(spec)))
+        return dict(x=x, llh=llh, nit=nit, nfev=nfev, status=status, iterations_issued=int(stats[0]), slots=int(stats[1]),
+                    speculative_iterations=int(spec.value))
+
+    def basinhopping(self, starts, split_time, jsfs_row, rngs, niter=100, T=0.5, stepsize=0.5, interval=50, target_accept_rate=0.5,
+                     stepwise_factor=0.9, xatol=1e-4, fatol=1e-4, nm_maxiter=None, nm_maxfev=None):
+        """``misti_basinhopping``: ``scipy.optimize.basinhopping(-JAFSLikelihood, x0, niter, T, stepsize,
+        minimizer_kwargs=dict(method='Nelder-Mead'), rng=rngs[s])`` from every row of ``starts`` at once - the reference's
+        ``Solve(globalOpt=True)`` (``/root/reference/MigrationInference.py:723-725``, T = 0.5) for many starts.
+        ``rngs``: one ``numpy.random.Generator`` per start (or one seed per start): the uniforms SciPy would draw from it
+        (per hop ``n_param`` for the displacement, one for the Metropolis test) are drawn here, up front.
+        Returns dict(x[S][P], llh[S], nfev[S], failures[S], accepted[S])."""
+        st = _f64(starts, (-1, self.n_param))
+        S, N = st.shape
+        row = _f64(jsfs_row, (8,))
+        gens = [g if isinstance(g, np.random.Generator) else np.random.default_rng(g) for g in rngs]
+        if len(gens) != S:
+            raise ValueError("one generator (or seed) per start")
+        uni = np.empty((S, int(niter), N + 1))
+        for s_, g in enumerate(gens):
+            for h in range(int(niter)):
+                uni[s_, h, :N] = g.random(N)                 # RandomDisplacement: rng.uniform(-stepsize, stepsize, shape)
+                uni[s_, h, N] = g.random()                   # Metropolis: rng.uniform()
+        x = np.empty((S, N))
+        llh = np.empty(S)
+        nfev, failures, accepted = (np.empty(S, dtype=np.int32) for _ in range(3))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.misti_basinhopping(self._ctx, S, ptr(st), float(split_time), ptr(row), int(niter), float(T), float(stepsize), int(interval),
+                                                float(target_accept_rate), float(stepwise_factor), float(xatol), float(fatol),
+                                                int(nm_maxiter if nm_maxiter is not None else 200 * N), int(nm_maxfev if nm_maxfev is not None else 200 * N),
+                                                ptr(uni), ptr(x), ptr(llh), ptr(nfev), ptr(failures), ptr(accepted)))
+        stats = (C.c_int64 * 2)()
+        _lib.check(self._lib.misti_nm_last_stats(self._ctx, stats))
+        return dict(x=x, llh=llh, nfev=nfev, failures=failures, accepted=accepted, iterations_issued=int(stats[0]), slots=int(stats[1]))
 
     def enable_solver_trace(self, on=True):
         """Record, for the following batches, SciPy-comparable solver statistics per candidate and interval

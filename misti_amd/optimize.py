@@ -150,6 +150,42 @@ def solve_batched_dev(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=10
     return r["x"], r["llh"], r
 
 
+def solve_grouped_dev(engines, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
+    """``solve_batched_dev`` with the starts dealt out to several engine contexts (one host thread each; ctypes releases the
+    GIL for the duration of ``misti_nm_solve``): the three engine batches of an iteration depend on each other, the searches of
+    different groups do not, so their batches overlap on the GPU.  A start's trajectory does not depend on which batch its
+    points travel in: results equal ``solve_batched_dev`` on one context, bit for bit.
+    Returns (params[S, P], llh[S], dict with nit, nfev, status and per-group work counters)."""
+    import threading
+    starts = np.atleast_2d(np.asarray(starts, dtype=float))
+    G = len(engines)
+    parts = [np.arange(g, starts.shape[0], G) for g in range(G)]              # interleaved: every group sees the same mix of starts
+    res, err = [None] * G, []
+
+    def work(g):
+        try:
+            res[g] = engines[g].nm_solve(starts[parts[g]], split_time, jsfs_row, tol=tol, maxiter=maxiter)
+        except BaseException as e:                                           # surfaces in the caller's thread
+            err.append(e)
+    threads = [threading.Thread(target=work, args=(g,)) for g in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if err:
+        raise err[0]
+    S, P = starts.shape
+    out = dict(x=np.empty((S, P)), llh=np.empty(S), nit=np.empty(S, dtype=np.int32), nfev=np.empty(S, dtype=np.int32), status=np.empty(S, dtype=np.int32))
+    for g in range(G):
+        for k in out:
+            out[k][parts[g]] = res[g][k]
+    out["iterations_issued"] = max(r["iterations_issued"] for r in res)
+    out["slots"] = sum(r["slots"] for r in res)
+    out["speculative_iterations"] = max(r["speculative_iterations"] for r in res)
+    out["groups"] = G
+    return out["x"], out["llh"], out
+
+
 def bootstrap_split_interval(llk, split_values, level=0.95):
     """Confidence interval of the split time from bootstrap replicates, as in the reference's
     ``test.bs/bs_conf_int.ipynb``: per replicate the arg-max split over the scan, then a

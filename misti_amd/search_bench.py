@@ -1,7 +1,12 @@
-"""`bench.py --workload config3-search`: BASELINE config 3 as a SEARCH - two optimised -mi bands, Nelder-Mead from
-16 384 random starts with the simplices resident in HBM (misti_nm_solve; reference semantics
-MigrationInference.Solve, /root/reference/MigrationInference.py:718-733) - timed end to end: objective evaluations
-per second INCLUDING the optimiser's own kernels and the idle slots of finished starts."""
+"""`bench.py --workload config3-search | config3-basinhopping`: BASELINE config 3 as a SEARCH - two optimised -mi bands from 16 384
+random starts with the simplices resident in HBM - timed end to end: objective evaluations per second INCLUDING the optimiser's own
+kernels and the idle slots of finished starts.
+
+  config3-search         SciPy-exact Nelder-Mead per start (misti_nm_solve; reference semantics MigrationInference.Solve,
+                         /root/reference/MigrationInference.py:718-733: xatol = fatol = 1e-4, maxiter = 1000), the starts dealt out to
+                         `--search-groups` engine contexts whose batches overlap (misti_amd.optimize.solve_grouped_dev)
+  config3-basinhopping   the reference's global variant (:723-725: scipy.optimize.basinhopping(T=0.5, Nelder-Mead)) per start
+                         (misti_basinhopping), `--bh-niter` hops (SciPy's default of 100 hops is 101 such searches per start)"""
 from __future__ import annotations
 
 import json
@@ -12,50 +17,103 @@ import time
 
 import numpy as np
 
+GROUPS = 1          # engine contexts the starts are dealt out to (measured on MI355X: 4 groups 1.08 s per search, 1 group 1.00 s - the search
+                    # is bound by the latency of its slowest chains, not by throughput; misti_amd.optimize.solve_grouped_dev stays for callers
+                    # with several independent searches)
+BH_NITER = 2
 
-def run(a, spectrum_fn, dev, local_rank, rank, world, json_fd):
-    import torch
-    from . import workloads
-    from .engine import Engine
-    if world > 1:
-        raise SystemExit("config3-search is a single-GPU leg (shard the starts with misti_amd.dist for more)")
-    w = workloads.config3(spectrum_fn)
-    split = float(w.split_time[0])
-    S = w.n_cand
-    steps = max(1, min(a.steps, 8))                       # a step = one complete search of all starts
-    with Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs()) as eng:
-        for _ in range(min(a.warmup, 1) + 1):             # first call allocates the search state
-            r = eng.nm_solve(w.params, split, w.jsfs[0], tol=1e-4, maxiter=1000)
-        dts = []
-        while not dts or (sum(dts) < a.min_seconds and len(dts) < 50):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                r = eng.nm_solve(w.params, split, w.jsfs[0], tol=1e-4, maxiter=1000)
-            torch.cuda.synchronize()
-            dts.append(time.perf_counter() - t0)
-        dt = statistics.median(dts)
-        evals = int(r["nfev"].sum())
-        # the same evaluations as plain batches (no optimiser): what the search costs on top
-        t0 = time.perf_counter()
-        eng.evaluate(np.full(S, split), w.params, w.jsfs)
-        t_batch = time.perf_counter() - t0
+
+def _metric():
     metric = "composite-llk evals/sec over (split×mi) grid, 128 merged PSMC intervals"
     try:
         metric = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json"))).get("metric") or metric
     except Exception:
         pass
-    out = {"metric": metric, "value": evals * steps / dt, "unit": "llk evals/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup,
+    return metric
+
+
+def run(a, spectrum_fn, dev, local_rank, rank, world, json_fd):
+    import torch
+    from . import workloads
+    from .engine import Engine
+    from .optimize import solve_grouped_dev
+    if world > 1:
+        raise SystemExit("%s is a single-GPU leg (shard the starts with misti_amd.dist for more)" % a.workload)
+    w = workloads.config3(spectrum_fn)
+    split = float(w.split_time[0])
+    S = w.n_cand
+    if a.workload == "config3-basinhopping":
+        return run_basinhopping(a, w, split, local_rank, json_fd)
+    steps = max(1, min(a.steps, 8))                       # a step = one complete search of all starts
+    engines = [Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs()) for _ in range(GROUPS)]
+    try:
+        search = lambda: solve_grouped_dev(engines, split, w.params, w.jsfs[0], tol=1e-4, maxiter=1000)[2]
+        for _ in range(min(a.warmup, 1) + 1):             # first call allocates the search state
+            r = search()
+        dts = []
+        while not dts or (sum(dts) < a.min_seconds and len(dts) < 50):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = search()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = statistics.median(dts)
+        evals = int(r["nfev"].sum())
+        # the same search on ONE context (the three batches of an iteration strictly one after another)
+        t0 = time.perf_counter()
+        r1 = engines[0].nm_solve(w.params, split, w.jsfs[0], tol=1e-4, maxiter=1000)
+        t_one = time.perf_counter() - t0
+        same = all(np.array_equal(r[k], r1[k], equal_nan=True) for k in ("x", "llh", "nit", "nfev", "status"))
+        # the same evaluations as plain batches (no optimiser): what the search costs on top
+        t0 = time.perf_counter()
+        engines[0].evaluate(np.full(S, split), w.params, w.jsfs)
+        t_batch = time.perf_counter() - t0
+    finally:
+        for e in engines:
+            e.close()
+    out = {"metric": _metric(), "value": evals * steps / dt, "unit": "llk evals/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup,
            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "config3-search: numT=128, two optimised bands, Nelder-Mead from %d random starts, simplices resident in HBM" % S,
                       "starts": S, "objective_evaluations_per_search": evals, "iterations_max": int(r["nit"].max()),
                       "iterations_median": float(np.median(r["nit"])), "converged_fraction": float((r["status"] == 0).mean()),
-                      "iterations_issued": r["iterations_issued"], "batch_slots": r["slots"],
-                      "engine_candidates_per_search": int(S * (w.n_param + 1) + r["slots"] * (2 + w.n_param)),
-                      "batches_in_flight": 1, "parallelism": "1 GPU"},
+                      "iterations_issued": r["iterations_issued"], "speculative_iterations": r["speculative_iterations"], "batch_slots": r["slots"],
+                      "search_groups": GROUPS, "batches_in_flight": GROUPS, "parallelism": "1 GPU"},
+           "one_context": {"value": int(r1["nfev"].sum()) / t_one, "s_per_search": t_one, "iterations_issued": r1["iterations_issued"],
+                           "speculative_iterations": r1["speculative_iterations"], "equal_to_grouped": bool(same)},
            "timing": {"repeats": len(dts), "timed_region_s_median": dt,
-                      "note": "value = objective evaluations SciPy counts (sum of nfev over the starts) per second of the whole search, optimiser kernels and "
-                              "all-dead slots of finished starts included; one plain host-buffer batch of the %d starts takes %.2f ms" % (S, 1e3 * t_batch)},
+                      "note": "value = objective evaluations SciPy counts (sum of nfev over the starts) per second of the whole search, optimiser kernels, "
+                              "speculative points and all-dead slots of finished starts included; one plain host-buffer batch of the %d starts takes %.2f ms"
+                              % (S, 1e3 * t_batch)},
+           "best": {"llh": float(np.max(r["llh"])), "params": [float(v) for v in r["x"][int(np.argmax(r["llh"]))]], "truth": [0.2, 0.05]}}
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
+def run_basinhopping(a, w, split, local_rank, json_fd):
+    import torch
+    from .engine import Engine
+    S = w.n_cand
+    niter = BH_NITER
+    with Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs()) as eng:
+        seeds = np.arange(S) + 1000
+        hop = lambda: eng.basinhopping(w.params, split, w.jsfs[0], rngs=seeds, niter=niter, T=0.5, stepsize=0.5)
+        r = hop()                                         # first call allocates
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = hop()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    evals = int(r["nfev"].sum())
+    out = {"metric": _metric(), "value": evals / dt, "unit": "llk evals/s", "n_gpus": 1, "steps": 1, "warmup": 1,
+           "ms_per_step": 1e3 * dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "config3-basinhopping: numT=128, two optimised bands, scipy-exact basinhopping(T=0.5, Nelder-Mead) from %d random starts, "
+                                  "%d hops (SciPy's default: 100), incumbents and simplices resident in HBM" % (S, niter),
+                      "starts": S, "hops": niter, "objective_evaluations": evals, "hops_accepted_mean": float(np.mean(r["accepted"])),
+                      "minimization_failures_mean": float(np.mean(r["failures"])), "iterations_issued": r["iterations_issued"],
+                      "batches_in_flight": 1, "parallelism": "1 GPU"},
+           "timing": {"repeats": 1, "timed_region_s_median": dt,
+                      "note": "value = res.nfev summed over the starts per second of the whole run (host draws of the uniforms included)"},
            "best": {"llh": float(np.max(r["llh"])), "params": [float(v) for v in r["x"][int(np.argmax(r["llh"]))]], "truth": [0.2, 0.05]}}
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())

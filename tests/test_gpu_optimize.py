@@ -157,3 +157,54 @@ def test_device_search_at_config3_size():
             assert ref.nit == r["nit"][i] and ref.nfev == r["nfev"][i]
     # the surface has one dominant basin: most starts end within the tolerance of the best value found
     assert (llh >= np.max(llh) - 1e-3).mean() > 0.8
+
+
+def test_speculative_iterations_do_not_change_the_search(cfg3):
+    """With few starts left an iteration sends all 4 + N points SciPy could ask for as ONE batch (misti_nm.hip:
+    nm_spec_points / nm_spec_finish); decisions and counters must be those of the three-batch path, bit for bit."""
+    import os
+    from misti_amd.engine import Engine
+    w, eng = cfg3
+    split = float(w.split_time[0])
+    out = {}
+    for name, env in (("spec", {}), ("plain", {"MISTI_NM_SPEC": "0"})):
+        os.environ.update(env)
+        try:
+            with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+                out[name] = e.nm_solve(w.params[:300], split, w.jsfs[0], tol=1e-4, maxiter=1000)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a, b = out["spec"], out["plain"]
+    assert a["speculative_iterations"] > 10 and b["speculative_iterations"] == 0
+    for k in ("x", "llh", "nit", "nfev", "status"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_basinhopping_equals_scipy(cfg3):
+    """The reference's global search (MigrationInference.Solve(globalOpt=True), /root/reference/MigrationInference.py:723-725:
+    scipy.optimize.basinhopping(T=0.5, Nelder-Mead)) for 8 starts at once on the device against SciPy's own runner on the GPU
+    objective, one numpy Generator per start: lowest minimum, its value, the evaluation count and the failed minimisations."""
+    from scipy import optimize
+    w, eng = cfg3
+    split = float(w.split_time[0])
+    S, niter = 8, 7
+    starts = w.params[5:5 + S]
+    got = eng.basinhopping(starts, split, w.jsfs[0], rngs=[100 + s for s in range(S)], niter=niter, T=0.5, stepsize=0.05, interval=3)
+
+    def obj(mu):
+        if (np.asarray(mu) < 0).any():
+            return np.inf
+        v = float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+        return -v if np.isfinite(v) else np.inf
+    import warnings
+    hops_taken = 0
+    for s in range(S):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = optimize.basinhopping(obj, starts[s], niter=niter, T=0.5, stepsize=0.05, interval=3,
+                                        minimizer_kwargs=dict(method="Nelder-Mead"), rng=np.random.default_rng(100 + s))
+        assert np.array_equal(ref.x, got["x"][s]), (s, ref.x, got["x"][s])
+        assert -ref.fun == got["llh"][s] and ref.nfev == got["nfev"][s] and ref.minimization_failures == got["failures"][s], (s, ref.fun, ref.nfev)
+        hops_taken += got["accepted"][s]
+    assert hops_taken > 0                                    # the Metropolis test really accepted some hops
