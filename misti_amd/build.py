@@ -41,6 +41,22 @@ def build(force=False, verbose=False, extra=(), out=None):
     target = out or LIB
     if not force and not out and not stale():
         return LIB
+    # Several processes may get here at once (every rank of `bench.py --gpus N` imports the package after a checkout or an edit):
+    # one builds, the others wait for the lock and find the library fresh; the compiler writes to a per-process name and the
+    # finished file is moved into place, so nobody ever maps a half-written library.
+    import fcntl
+    lock = open(target + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not out and not stale():
+            return LIB
+        return _build_locked(target, verbose, extra)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(target, verbose, extra):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
            "-Wall", "-Wno-unused-function"]
     # Contraction within a source expression only (clang's `on`), not `fast`: with `fast` the backend fuses a multiply
@@ -54,11 +70,16 @@ def build(force=False, verbose=False, extra=(), out=None):
     if os.environ.get("MISTI_STAMP"):          # diagnostic build: per-section cycle stamps in the correction kernel
         cmd += ["-DMISTI_STAMP=1"]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", target + ".tmp"]
+    tmp = "%s.%d.tmp" % (target, os.getpid())
+    cmd += ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    os.replace(target + ".tmp", target)
+    try:
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return target
 
 

@@ -351,3 +351,62 @@ def format_migration(model, llh, scale_time=1, scale_eps=1):
                 cols += [pair[0], pair[1]]
         o.write("RS\t" + "\t".join(str(v) for v in cols) + "\n")
     return o.getvalue()
+
+
+# ------------------------------------------------------ result reader ----
+class MigData:
+    """What ``ReadMigration`` returns (migrationIO.MigData, /root/reference/migrationIO.py:65-99): attribute names as there."""
+
+    def __init__(self):
+        self.llh = self.splitT = self.migStart = self.migEnd = self.times = None
+        self.lambda1 = self.lambda2 = self.lambdah1 = self.lambdah2 = self.thrh = self.mi = self.sampleDate = None
+        self.jaf = None
+        self.pr = None                 # [(p11_1, p11_2, p22_1, p22_2, p12_1, p12_2)] per RS row (zeros where the row has none)
+
+
+def read_migration(path_or_file, scale_time=1, scale_eps=1):
+    """Reader of the ``-o`` result file (``#MiSTI2 ver 0.3 / 0.4``; ``ReadMigration``, /root/reference/migrationIO.py:377-504,
+    without its plotting): times are scaled by the file's ``SCT`` (default ``scale_time``), rates are ``1 / N`` divided by
+    its ``SCE``.  ``jaf`` is a list (the reference leaves a ``map`` object)."""
+    fh = open(path_or_file) if isinstance(path_or_file, str) else path_or_file
+    d = MigData()
+    times, lc1, lc2, lh1, lh2, pr = [], [], [], [], [], []
+    try:
+        head = next(fh).rstrip().split(" ")
+        if head[0] != "#MiSTI2":
+            raise ValueError("not a #MiSTI2 result file (the pre-0.3 format is not supported)")
+        version = float(head[2])
+        if version < 0.3:
+            raise ValueError("File version is not supported anymore.")
+        for line in fh:
+            f = line.rstrip("\n").split("\t")
+            tag = f[0]
+            if tag == "LK":
+                d.llh = float(f[1])
+            elif tag == "ST":
+                d.splitT = int(f[1])
+            elif tag == "SD":
+                d.sampleDate = int(f[1])
+            elif tag == "TR":
+                d.thrh = [float(f[1]), float(f[2])]
+            elif tag == "SFS":
+                d.jaf = [float(v) for v in f[1:]]
+            elif tag == "SCT":
+                scale_time = float(f[1])
+            elif tag == "SCE":
+                scale_eps = float(f[1])
+            elif tag == "RS":
+                times.append(float(f[1]) * scale_time)
+                lc1.append(1.0 / float(f[2]) / scale_eps)
+                lc2.append(1.0 / float(f[3]) / scale_eps)
+                shift = 0
+                if version >= 0.4:
+                    lh1.append(1.0 / float(f[4]) / scale_eps)
+                    lh2.append(1.0 / float(f[5]) / scale_eps)
+                    shift = 2
+                pr.append(tuple(float(v) for v in f[6 + shift:12 + shift]) if len(f) > 6 + shift else (0,) * 6)
+    finally:
+        if isinstance(path_or_file, str):
+            fh.close()
+    d.times, d.lambda1, d.lambda2, d.lambdah1, d.lambdah2, d.pr = times, lc1, lc2, lh1, lh2, pr
+    return d

@@ -466,7 +466,16 @@ def host_fixtures(tmp):
             migrationIO.OutputMigration("", list(params), m, 1234.5, 0.75)
         text = out.getvalue()
         text = text[text.index("#MiSTI2"):]
-        writer.append({"name": name, "in": {"times": T, "lambdas": L, "sfs": S, "split": split, "mi": mi, "pu": pu, "params": params,
+        # ... and what the reference's own reader of that format makes of it (migrationIO.ReadMigration :377-504, no plotting)
+        fm = os.path.join(tmp, "w_%s.mi" % name)
+        open(fm, "w").write(text)
+        with contextlib.redirect_stdout(io.StringIO()):
+            rd = migrationIO.ReadMigration(fm)
+        read_back = {"llh": raw(rd.llh), "splitT": rd.splitT, "sampleDate": rd.sampleDate, "thrh": raw(rd.thrh), "jaf": [float(v) for v in rd.jaf],
+                     "times": raw(rd.times), "lambda1": raw(rd.lambda1), "lambda2": raw(rd.lambda2), "lambdah1": raw(rd.lambdah1),
+                     "lambdah2": raw(rd.lambdah2), "migStart": rd.migStart, "migEnd": rd.migEnd, "mi": rd.mi}
+        writer.append({"name": name, "read_back": read_back,
+                       "in": {"times": T, "lambdas": L, "sfs": S, "split": split, "mi": mi, "pu": pu, "params": params,
                                             "kw": kw, "thrh": [0.0521, 0.0104], "scaleTime": 1234.5, "scaleEPS": 0.75},
                        # attribute values as the reference holds them (Python ints stay ints: str(0) != str(0.0) in the text)
                        "model": {"times": raw(m.times), "splitT": m.splitT, "sampleDate": m.sampleDate, "thrh": raw(m.thrh),

@@ -200,3 +200,24 @@ def test_engine_context_is_not_destroyed_from_another_process():
     e._pid = os.getpid()
     e.close()
     assert e._lib.destroyed == 1 and not e._ctx
+
+
+def test_read_migration_against_the_reference_reader(tmp_path):
+    """io.read_migration on the reference's own OutputMigration text against what migrationIO.ReadMigration (:377-504) made
+    of the same file (tests/golden/golden_host.json: writer[*].read_back, generated by make_golden.py)."""
+    import io as _io
+    from misti_amd import io as mio
+    host = json.load(open(os.path.join(GOLDEN, "golden_host.json")))
+    assert len(host["writer"]) == 3
+    for w in host["writer"]:
+        want = w["read_back"]
+        f = tmp_path / (w["name"] + ".mi")
+        f.write_text(w["text"])
+        for src in (str(f), _io.StringIO(w["text"])):
+            d = mio.read_migration(src)
+            assert d.llh == want["llh"] and d.splitT == want["splitT"] and d.sampleDate == want["sampleDate"] and d.thrh == want["thrh"]
+            assert d.jaf == want["jaf"] and d.times == want["times"]
+            assert d.lambda1 == want["lambda1"] and d.lambda2 == want["lambda2"] and d.lambdah1 == want["lambdah1"] and d.lambdah2 == want["lambdah2"]
+            assert d.migStart is None and d.migEnd is None and d.mi is None
+        # round trip: the writer's own text of the same model reads back to the same numbers
+        assert len(d.pr) == len(d.times) and any(any(v != 0 for v in row) for row in d.pr)
