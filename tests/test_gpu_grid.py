@@ -47,10 +47,9 @@ def test_grid_sample_against_oracle(cfg2):
                 np.testing.assert_allclose(res.jafs[c], oracle_batch.last_jafs[k], rtol=1e-9)
     assert n_reg >= 60 and n_out <= max(1, n_reg // 100)
     # runaway-rate candidates: the per-candidate contract (1e-9, or 10 x that candidate's own spread under eight 2^-48
-    # perturbations, measured here through the compiled baseline).  Measured on MI355X: 82 tight, 13 within their spread, ONE
-    # outside (candidate 3 491 of the chain of rate index 35: 1.9e-6, rate x length 1 846)
+    # perturbations, measured here through the compiled baseline).  Measured on MI355X: 85 tight, 11 within their spread, none outside
     rep = baseline_contract(w, idx, res.llk, res.status)
-    assert len(rep["mismatch"]) == 0 and len(rep["outside"]) <= 2, [(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]]
+    assert len(rep["mismatch"]) == 0 and len(rep["outside"]) <= 1, [(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]]
     for k in rep["outside"]:
         assert rep["run"][k] >= RUNAWAY and rep["rel"][k] <= 1e-5, (int(idx[k]), rep["rel"][k], rep["run"][k])
     # the engine's own diagnostic agrees with the oracle's measure of the same quantity
