@@ -1,4 +1,4 @@
-"""Randomised differential campaign as a test: 3 x 600 random models (numT 8-40, all flag combinations, bands in both
+"""Randomised differential campaign as a test: 4 x 600 random models (seed 4 held out until the code was frozen) (numT 8-40, all flag combinations, bands in both
 directions, pulses, ancient sample, fractional splits), each evaluated as ONE batch of 6-28 candidates through the C
 ABI - so chains are shared and the trunk paths run - against the oracle's value of every candidate
 (tests/golden/campaign_seed{1,2,3}.json.gz, written by `tools/random_campaign.py --make-ref`; 27 minutes of oracle time
@@ -18,10 +18,14 @@ pytestmark = pytest.mark.gpu
 # candidates OUTSIDE the contract, pinned by index with their measured distance as the bound.
 MEASURED = {1: dict(n=7648, tight=5249, outside={1941: 1e-6}),       # model 148 candidate 12 (--cpfit runaway, golden camp_m148_c12: 2.5e-7)
             2: dict(n=7694, tight=5379, outside={}),
-            3: dict(n=7434, tight=5145, outside={})}
+            3: dict(n=7434, tight=5145, outside={}),
+            # held out: generated in round 3 after the solver code was frozen (first pass with 4 perturbations per noise-class candidate:
+            # 13 outside, 9 status mismatches - three chains and one; the reference's 16-perturbation and one-ulp studies of those 22,
+            # profiles/r03_random_campaign_seed4_heldout.txt, then show it moving as far itself)
+            4: dict(n=7579, tight=5097, outside={})}
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_random_batches_against_the_oracle(seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import random_campaign as rc
