@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MISTI_ABI_VERSION 2
+#define MISTI_ABI_VERSION 3
 
 /* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
 #define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */

@@ -21,7 +21,7 @@ STATUS_TEXT = {
     6: "Stiff interval: the contour solver (rate x length > 96) did not converge",
 }
 MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
-ABI_VERSION = 2
+ABI_VERSION = 3
 TRACE_MAX_CAND, TRACE_MAX_ITER = 64, 200
 
 

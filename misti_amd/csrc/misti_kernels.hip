@@ -2512,11 +2512,24 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
         for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
         __syncthreads();
         auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[key(split_time[i])], 1);
+        // one block for the whole batch: four candidates per thread and trip (a trip is a global load and a shared-memory atomic
+        // one after the other; at 65 536 candidates the plain loop was 0.12 ms of a 2.3 ms batch)
+        const int64_t step = 4 * (int64_t)blockDim.x;
+        for (int64_t i0 = threadIdx.x; i0 < n; i0 += step) {
+            double st[4];
+            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
+            for (int u = 0; u < 4; ++u) if (i0 + u * (int64_t)blockDim.x < n) atomicAdd(&hist[key(st[u])], 1);
+        }
         __syncthreads();
         if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
         __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { int pos = atomicAdd(&hist[key(split_time[i])], 1); order[pos] = (int32_t)i; }
+        for (int64_t i0 = threadIdx.x; i0 < n; i0 += step) {
+            double st[4];
+            int pos[4];
+            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
+            for (int u = 0; u < 4; ++u) pos[u] = i0 + u * (int64_t)blockDim.x < n ? atomicAdd(&hist[key(st[u])], 1) : 0;
+            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; if (i < n) order[pos[u]] = (int32_t)i; }
+        }
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 
 # Measured on MI355X with this round's build (profiles/r03_random_campaign_seed{1,2,3}.txt): candidates within 1e-9 and the
 # candidates OUTSIDE the contract, pinned by index with their measured distance as the bound.
-MEASURED = {1: dict(n=7648, tight=5249, outside={1941: 1e-6}),       # model 148 candidate 12 (--cpfit runaway, golden camp_m148_c12: 2.5e-7)
-            2: dict(n=7694, tight=5379, outside={}),
-            3: dict(n=7434, tight=5145, outside={}),
+MEASURED = {1: dict(n=7648, comparable=7103, tight=5249, outside={1941: 1e-6}),       # model 148 candidate 12 (--cpfit runaway, golden camp_m148_c12: 2.5e-7)
+            2: dict(n=7694, comparable=7080, tight=5379, outside={}),
+            3: dict(n=7434, comparable=6811, tight=5145, outside={}),
             # held out: generated in round 3 after the solver code was frozen (first pass with 4 perturbations per noise-class candidate:
             # 13 outside, 9 status mismatches - three chains and one; the reference's 16-perturbation and one-ulp studies of those 22,
             # profiles/r03_random_campaign_seed4_heldout.txt, then show it moving as far itself)
-            4: dict(n=7579, tight=5097, outside={})}
+            4: dict(n=7579, comparable=6779, tight=5097, outside={})}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
@@ -40,7 +40,7 @@ def test_random_batches_against_the_oracle(seed):
     # failure against value only where the reference itself flips under a 2^-48 perturbation: none measured, none allowed
     assert s["status_mismatch"] == 0, rep["bad"][:5]
     comparable = s["tight"] + s["self_bound"] + s["internal_bound"] + s["outside"]
-    assert comparable >= want["n"] - 700                  # the rest fails on both sides (negative rates, failed corrections)
+    assert comparable >= want["comparable"] - 5           # the rest fails on both sides (negative rates, failed corrections) or is a reference flip
     # the contract per candidate (tests/parity.py): 1e-9 (+ rounding floor), or 10 x the reference's own spread under 4-64
     # perturbations of 2^-48 for THAT candidate, or under one ulp in its own pair-chain expm
     assert s["tight"] >= want["tight"] - comparable // 100, (s["tight"], want["tight"])

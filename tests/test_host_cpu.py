@@ -100,8 +100,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.misti_abi_version() == 2 == _lib.ABI_VERSION
-    assert "#define MISTI_ABI_VERSION 2" in hdr
+    assert lib.misti_abi_version() == 3 == _lib.ABI_VERSION
+    assert "#define MISTI_ABI_VERSION 3" in hdr
 
 
 def test_tables_match_oracle_structure():
