@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Gain ratio and gradient norm of every trust-region step of one lambda-correction solve, in float64 as the oracle (= the reference's
+SciPy calls) evaluates them and in 60-digit arithmetic (mpmath): how far from SciPy's thresholds (radius doubled when the ratio
+exceeds 0.75, stop when |J^T f| < 1e-10) the reference's own decisions sit.  CPU only.
+
+    python tools/gain_ratio_study.py CANDIDATE [WORKLOAD [SOLVE]]      # default: config2, the solve with the most evaluations; SOLVE -1: config 5's interval 81
+    python tools/gain_ratio_study.py 3427 config2 > profiles/rNN_gain_ratio_study.txt"""
+import os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+warnings.simplefilter('ignore')
+import numpy as np, mpmath as mp
+mp.mp.dps = 50
+from misti_amd import workloads
+import oracle.misti_oracle as mo
+from oracle.batch import oracle_eval, oracle_truth_spectrum
+wl = sys.argv[2] if len(sys.argv) > 2 else 'config2'
+w = getattr(workloads, wl)(oracle_truth_spectrum)
+c = int(sys.argv[1]) if len(sys.argv) > 1 else 3427
+which = int(sys.argv[3]) if len(sys.argv) > 3 else None
+s, p = float(w.split_time[c]), list(w.params[c])
+grab = []
+class G(mo._PairChain):
+    def solve_lambda_system(self, cpfit=True, prec=1e-10, norm_eps=0.02):
+        self._n = 0
+        r = super().solve_lambda_system(cpfit, prec, norm_eps)
+        if self._n > 0: grab.append(dict(mu=self._mu_s, lh=self._lh_s, P0=[list(map(float, q)) for q in self.P0], evals=self._log))
+        return r
+    def _residual_cp(self, l):
+        if self._n == 0:
+            self._mu_s, self._lh_s, self._log = list(self.mu), list(self.lh), []
+        self._n += 1
+        r = super()._residual_cp(l)
+        self._log.append((tuple(map(float, l)), tuple(map(float, r))))
+        return r
+old = mo._PairChain; mo._PairChain = G
+try:
+    oracle_eval(w.times, w.lh, w.bands, w.pulses, w.flags, w.sample_date, s, p, w.jsfs)
+finally:
+    mo._PairChain = old
+g = grab[-1]                      # interval 84 is the last migrating solve of this candidate? check nfev
+lens = [len(x['evals']) for x in grab]
+k = int(np.argmax(lens)) if which is None else (which if which >= 0 else [i for i, x in enumerate(grab) if abs(x['lh'][0] - 0.07221297608789039) < 1e-12][0]); g = grab[k]
+print('solve', k, 'of', len(grab), 'evals', lens[k], 'mu', g['mu'], 'lh', g['lh'])
+mu0, mu1 = g['mu']; P0 = g['P0']; lh = g['lh']
+def f_exact(x):
+    M = mp.matrix([[-2*mu0 - x[0], 0, mu1], [0, -2*mu1 - x[1], mu0], [2*mu0, 2*mu1, -mu0 - mu1]])
+    E = mp.expm(M)
+    out = []
+    for kk in (0, 1):
+        v = E * mp.matrix(P0[kk])
+        out.append(sum(v) - mp.e ** (-mp.mpf(lh[kk])) * sum(mp.mpf(q) for q in P0[kk]))
+    return out
+# reconstruct iterates: evaluations come in groups base, +h0, +h1
+ev = g['evals']
+bases = [(ev[i], ev[i+1], ev[i+2]) for i in range(0, len(ev) - 2, 3)]
+def ratio_from(fb, fa, fc, xb, xa, xc, xn, fn):
+    J = [[(fa[0]-fb[0])/(xa[0]-xb[0]), (fc[0]-fb[0])/(xc[1]-xb[1])], [(fa[1]-fb[1])/(xa[0]-xb[0]), (fc[1]-fb[1])/(xc[1]-xb[1])]]
+    pstep = [xn[0]-xb[0], xn[1]-xb[1]]
+    gk = [J[0][0]*fb[0] + J[1][0]*fb[1], J[0][1]*fb[0] + J[1][1]*fb[1]]
+    Jp = [J[0][0]*pstep[0] + J[0][1]*pstep[1], J[1][0]*pstep[0] + J[1][1]*pstep[1]]
+    pred = -(0.5*(Jp[0]**2 + Jp[1]**2) + pstep[0]*gk[0] + pstep[1]*gk[1])
+    act = 0.5*(fb[0]**2+fb[1]**2) - 0.5*(fn[0]**2+fn[1]**2)
+    return act/pred
+for i in range(len(bases) - 1):
+    (xb, fb), (xa, fa), (xc, fc) = bases[i]
+    (xn, fn) = bases[i+1][0]
+    r64 = ratio_from(fb, fa, fc, xb, xa, xc, xn, fn)
+    fbe, fae, fce, fne = f_exact(xb), f_exact(xa), f_exact(xc), f_exact(xn)
+    rex = ratio_from(fbe, fae, fce, [mp.mpf(v) for v in xb], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc], [mp.mpf(v) for v in xn], fne)
+    def gn(fb, fa, fc, xb, xa, xc):
+        J = [[(fa[0]-fb[0])/(xa[0]-xb[0]), (fc[0]-fb[0])/(xc[1]-xb[1])], [(fa[1]-fb[1])/(xa[0]-xb[0]), (fc[1]-fb[1])/(xc[1]-xb[1])]]
+        return max(abs(J[0][0]*fb[0] + J[1][0]*fb[1]), abs(J[0][1]*fb[0] + J[1][1]*fb[1]))
+    g64 = gn(fb, fa, fc, xb, xa, xc); gex = gn(fbe, fae, fce, [mp.mpf(v) for v in xb], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc])
+    print('it', i, 'x (%.4f, %.4f)' % xb, 'ratio f64 %.6f exact %.6f' % (r64, float(rex)), ' g_norm f64 %.4e exact %.4e' % (g64, float(gex)))
