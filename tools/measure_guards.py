@@ -10,6 +10,7 @@ from misti_amd import workloads
 from misti_amd.engine import Engine, truth_spectrum
 import test_gpu_fullsize as tf
 spec = lambda *a: truth_spectrum(*a)
+print('# checker: the compiled CPU baseline (oracle/cpu/misti_cpu.cpp, the reference\'s algorithm restated, pinned on the reference-generated goldens), values and\n# spreads (eight 2^-48 perturbations per candidate that is not within 1e-9) - not /root/reference itself')
 for name, idxf in (("config2", lambda w: np.arange(w.n_cand)), ("config5", lambda w: np.arange(0, w.n_cand, 16)), ("config3", lambda w: np.arange(0, w.n_cand, 4))):
     w = getattr(workloads, name)(spec)
     rep = tf.full_contract(w, idxf(w))

@@ -180,6 +180,8 @@ def compare(cases, ref, dump=""):
 
 def print_report(rep):
     stats = rep["stats"]
+    print("# reference values and spreads of this report: the NumPy/SciPy ORACLE (oracle/misti_oracle.py: the reference's own SciPy calls; agrees with the")
+    print("# reference to <= 1e-12, bit for bit on almost every case, on the 168 reference-generated goldens), not /root/reference itself")
     print(stats)
     print("within 1e-9 (+ rounding floor): %d, worst %.3g" % (stats["tight"], rep["worst_tight"]))
     print("within 10 x the reference's own measured spread under input perturbations: %d, worst factor %.2f" % (stats["self_bound"], rep["worst_factor"]))
