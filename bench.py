@@ -576,16 +576,25 @@ def main():
         if world > 1:
             # both scalings in one line: the headline leg is one of them, the other one here
             other = "strong" if a.scaling == "weak" else "weak"
-            o_leg = leg("config5" if other == "strong" else "config2", other, short, min(a.warmup, 16), a.min_seconds, n_streams, serial_pass=False)
-            extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, interleaved" if other == "strong"
-                                 else "every rank its own config-2 grid")
             extra[a.scaling] = block(main_leg, "the headline leg above")
+            try:                                   # a secondary leg must never cost the headline line (the same code runs on every rank)
+                o_leg = leg("config5" if other == "strong" else "config2", other, short, min(a.warmup, 16), a.min_seconds, n_streams, serial_pass=False)
+                extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, interleaved" if other == "strong"
+                                     else "every rank its own config-2 grid")
+            except Exception as e:                 # noqa: BLE001
+                extra[other] = {"error": "%s: %s" % (type(e).__name__, e)}
         elif a.workload == "config2":
             # ONE call on ONE stream at the overlapped rate: 16 config-2 grids with distinct rate axes in one batch
-            s_leg = leg("config2x16", "weak", max(4, min(a.steps, 32)), 4, a.min_seconds, 1, serial_pass=True)
-            extra["single_call"] = block(s_leg, "16 config-2 grids with distinct rate axes (65 536 candidates, 1 024 chains) as ONE misti_eval_batch_dev "
-                                                "call per step, strictly one after another on ONE stream")
-            extra["host_abi"] = host_abi_leg("config2", max(16, min(a.steps, 128)))
+            try:
+                s_leg = leg("config2x16", "weak", max(4, min(a.steps, 32)), 4, a.min_seconds, 1, serial_pass=True)
+                extra["single_call"] = block(s_leg, "16 config-2 grids with distinct rate axes (65 536 candidates, 1 024 chains) as ONE misti_eval_batch_dev "
+                                                    "call per step, strictly one after another on ONE stream")
+            except Exception as e:                 # noqa: BLE001
+                extra["single_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                extra["host_abi"] = host_abi_leg("config2", max(16, min(a.steps, 128)))
+            except Exception as e:                 # noqa: BLE001
+                extra["host_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         out.update(extra)

@@ -112,11 +112,17 @@ def load(build_if_missing=True):
     except ImportError:
         pass
     lib = C.CDLL(path)
+    experimental = bool(os.environ.get("MISTI_LIB"))
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        try:
+            fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        except AttributeError:
+            if experimental:             # an older build loaded for an A/B measurement: its missing entry points simply cannot be called
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
-    if lib.misti_abi_version() != ABI_VERSION:
+    if lib.misti_abi_version() != ABI_VERSION and not experimental:
         raise MistiError(-1, "ABI version mismatch: %s is version %d, this binding expects %d (rebuild: python -m misti_amd.build --force)"
                          % (path, lib.misti_abi_version(), ABI_VERSION))
     _lib = lib

@@ -1484,13 +1484,6 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 }
                 xe[0] = lhs0; xe[1] = lhs1;
                 first = true; in_solve = true; spec_axis = -1;
-                // the previous solve's state dies here (the first evaluation overwrites all of it): said explicitly, so that none
-                // of it is live across the advance code above - the bounded 2-D fit of the default fit needs the registers
-                x[0] = x[1] = f[0] = f[1] = g[0] = g[1] = p[0] = p[1] = 0.0;
-                J[0][0] = J[0][1] = J[1][0] = J[1][1] = 0.0;
-                vk[0] = vk[1] = vk[2] = 0.0;
-                cost = Delta = alpha = predicted = 0.0;
-                nfev = 0; vk_base = 0;
                 break;
             }
             if (uni<GROUP>(!in_solve)) { active = false; break; }  // reached the split, or failed
