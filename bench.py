@@ -94,6 +94,8 @@ def parse(argv=None):
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed loop until the timed regions add up to this; the median is reported")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fit", default="", choices=("", "cpfit", "default"),
+                    help="override the workload's fitting mode: cpfit (--cpfit) or default (the reference's default: expected coalescence time)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the single_call / host_abi / strong blocks (headline leg only)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all_gather path even with one rank (rehearsal)")
     ap.add_argument("--dry-run", action="store_true",
@@ -282,13 +284,21 @@ def dry_run(a, json_fd):
     return 0 if ok else 1
 
 
+FIT_OVERRIDE = [""]
+
+
 def build_workload(name, spec):
     from misti_amd import workloads
-    return workloads.BUILDERS[name](spec)
+    w = workloads.BUILDERS[name](spec)
+    if FIT_OVERRIDE[0]:
+        w.flags = dict(w.flags, cpfit=FIT_OVERRIDE[0] == "cpfit")
+        w.name += " [fit overridden: %s]" % FIT_OVERRIDE[0]
+    return w
 
 
 def main():
     a = parse()
+    FIT_OVERRIDE[0] = a.fit
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(a)
     # stdout carries exactly one JSON line: libraries that print banners there (RCCL prints its version
@@ -610,6 +620,13 @@ def main():
         ab = algorithmic_bytes(w, R, mine)
         achieved = ab[dom] / (per_ms[dom] * 1e-3) / 1e9 if per_ms[dom] > 0 else 0.0
         out["roofline"] = roofline_block(a.workload, world, dom, per_ms, ab, achieved, n)
+        v = out["roofline"].get("valu")
+        if v and v.get("wave_insts"):
+            # the same counters at the rate of the headline leg: launches of the dominant kernel per second x its wave-instructions x 4 cycles,
+            # against all SIMD cycles of the chip - what share of the fp64 issue slots the OVERLAPPED run keeps busy
+            launches_per_s = a.steps / dt
+            v["frac_at_value"] = 4.0 * v["wave_insts"] * launches_per_s / (N_SIMD * GPU_CLOCK_HZ)
+            v["frac_at_value_note"] = "chip-wide share of fp64 VALU issue slots during the timed region of `value` (%d batches in flight)" % n_streams
         # secondary figure SURVEY 8d asks for: the flop model of an UNSHARED evaluation (what the reference computes per
         # candidate: ~16 sparse generator applications of 2 x 220 flop per two-population interval, ~5 kflop of 3x3
         # exponentials per migrating interval, 0.1 kflop per one-population interval) x distinct spectra per second,
