@@ -91,6 +91,12 @@ def parse(argv=None):
                     help="config2 (headline) | config2x16 | config3 | config4 | config5 | config3-search | config3-basinhopping")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
                     help="weak: every rank its own grid; strong: ONE grid sharded over the ranks (config4 / config5)")
+    ap.add_argument("--shard", default="chain", choices=("chain", "interleave"),
+                    help="strong scaling: deal whole lambda-correction chains to the ranks (default; a chain interleaved over the ranks is recomputed "
+                         "on every one of them) or interleave candidates (SURVEY 8e)")
+    ap.add_argument("--pretend-world", type=int, default=0,
+                    help="single GPU, --scaling strong: evaluate the shard rank 0 of an N-rank run would own (a per-rank cost model, not a scaling "
+                         "curve; the line says so in config.pretend_world and counts only that shard's candidates)")
     ap.add_argument("--min-seconds", type=float, default=0.25, help="repeat the K-step timed loop until the timed regions add up to this; the median is reported")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample (wall)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,7 +316,7 @@ def main():
         return dry_run(a, json_fd)
     import torch
     import torch.distributed as dist
-    from misti_amd.dist import env_rank, shard_indices
+    from misti_amd.dist import chain_shards, env_rank, shard_indices
     from misti_amd.engine import Engine, truth_spectrum
 
     rank, local_rank, world = env_rank()
@@ -346,8 +352,12 @@ def main():
         strong: ONE grid sharded over the ranks), W warmup steps first, the K-step region repeated until min_seconds."""
         w = build_workload(workload, spec)
         strong = scaling == "strong"
+        shards = None
         if strong:
-            mine = shard_indices(w.n_cand, rank, world, interleave=True)      # ONE grid, interleaved shards (SURVEY 8e)
+            # ONE grid: whole chains per rank (dist.chain_shards), or interleaved candidates (SURVEY 8e: every chain on every rank)
+            sw = a.pretend_world if (a.pretend_world > 1 and world == 1) else world
+            shards = chain_shards(w.params, w.n_cand, sw) if a.shard == "chain" else [shard_indices(w.n_cand, r, sw, interleave=True) for r in range(sw)]
+            mine = shards[rank]
         else:
             mine = np.arange(w.n_cand)
             if world > 1 and w.params is not None:
@@ -355,7 +365,7 @@ def main():
                 w.params = w.params * (1.0 + 0.01 * rank)
         n_total = w.n_cand
         n, R, P = len(mine), int(w.jsfs.shape[0]), w.n_param
-        per = -(-n_total // world) if strong else n                             # rows every rank contributes to the gather
+        per = max(len(x) for x in shards) if strong else n                      # rows every rank contributes to the gather (ragged shards padded)
         d_split = torch.as_tensor(w.split_time[mine], dtype=torch.float64, device=dev)
         d_par = torch.as_tensor(w.params[mine], dtype=torch.float64, device=dev).contiguous() if P else None
         d_jsfs = torch.as_tensor(w.jsfs, dtype=torch.float64, device=dev).contiguous()
@@ -446,6 +456,8 @@ def main():
         res = {"w": w, "mine": mine, "n": n, "n_total": n_total, "R": R, "P": P, "strong": strong, "bucket": bucket,
                "dts": dts, "dt": dt, "issue": host_issue[0], "steps": steps, "n_streams": len(lanes)}
         job_cands = n_total if strong else world * n          # candidates all ranks evaluate per step
+        if strong and a.pretend_world > 1 and world == 1:
+            job_cands = n                                     # a per-rank cost model: only rank 0's shard is evaluated, only it is counted
         res["job_cands"] = job_cands
         res["value"] = job_cands * R * steps / dt
         if serial_pass:
@@ -570,8 +582,8 @@ def main():
         "config": {"workload": w.name, "candidates_per_gpu": n, "candidates_total": job_cands, "replicates": R, "numT": w.numT,
                    "batches_in_flight": n_streams, "streams": n_streams,
                    "world_size": group_world, "candidates_per_rank": main_leg["cands_per_rank"], "chains_per_rank": main_leg["chains_per_rank"],
-                   "gather_bucket": bucket if use_dist else None,
-                   "parallelism": ("ONE grid sharded over the ranks (interleaved), all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket if strong else
+                   "gather_bucket": bucket if use_dist else None, "pretend_world": a.pretend_world if (a.pretend_world > 1 and world == 1 and strong) else None,
+                   "parallelism": ("ONE grid sharded over the ranks (%s), all_gather of llk (RCCL), one collective per %d batches of a lane" % ("whole chains per rank" if a.shard == "chain" else "interleaved", bucket) if strong else
                                    "every rank its own grid, all_gather of llk (RCCL), one collective per %d batches of a lane" % bucket) if world > 1 else "1 GPU"},
         "timing": {"repeats": len(dts), "timed_region_s_median": dt, "timed_region_s_total": sum(dts),
                    "timed_region_s_min": min(dts), "timed_region_s_max": max(dts),
@@ -589,7 +601,7 @@ def main():
             extra[a.scaling] = block(main_leg, "the headline leg above")
             try:                                   # a secondary leg must never cost the headline line (the same code runs on every rank)
                 o_leg = leg("config5" if other == "strong" else "config2", other, short, min(a.warmup, 16), a.min_seconds, n_streams, serial_pass=False)
-                extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, interleaved" if other == "strong"
+                extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, %s" % ("whole chains per rank" if a.shard == "chain" else "interleaved") if other == "strong"
                                      else "every rank its own config-2 grid")
             except Exception as e:                 # noqa: BLE001
                 extra[other] = {"error": "%s: %s" % (type(e).__name__, e)}

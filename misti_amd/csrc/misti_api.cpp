@@ -106,6 +106,8 @@ struct misti_ctx {
     int64_t trace_n = 0, trace_iter_cap = 0;   // candidates / chains covered by the trace of the last batch
     const int32_t* trace_of = nullptr;  // candidate -> chain of the last batch (device)
     hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
+    hipEvent_t last_ev = nullptr;       // recorded behind every batch: lets OTHER contexts see whether this one has work in flight
+    bool last_ev_set = false;
     DevBuf nm_f64, nm_i32;              // batched Nelder-Mead: simplices, points, counters (misti_nm_solve)
     int32_t* nm_live_host = nullptr;    // pinned: live starts after the last two finished iterations
     int64_t nm_iterations = 0;          // iterations issued by the last misti_nm_solve
@@ -119,6 +121,20 @@ struct misti_ctx {
 };
 
 namespace {
+
+// Every live context of the process, so that a batch can tell whether the device is busy with other contexts' batches (the
+// launch shape of mid-sized batches depends on it: latency when alone, throughput when not - misti_consts.h FOLLOW_BUSY_*).
+std::mutex g_ctx_mu;
+std::vector<misti_ctx*> g_ctxs;
+
+int other_contexts_busy(const misti_ctx* self) {
+    int busy = 0;
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    for (misti_ctx* o : g_ctxs)
+        if (o != self && o->device == self->device && o->last_ev_set && hipEventQuery(o->last_ev) == hipErrorNotReady) ++busy;
+    (void)hipGetLastError();                       // "not ready" is an answer, not an error to be found by the next launch check
+    return busy;
+}
 
 // Greedy runs of (numerically) constant lh, exactly as SmoothConst scans them
 // (MigrationInference.py:387-405): a run starts at k and takes every j with
@@ -330,7 +346,13 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // counts when batches overlap - unless it is known to collapse into a few long chains (pure latency: one chain
     // per wave and the trunk following it)
     auto shape = [&](int64_t est, int& cpw, bool& follow) {
-        const int64_t follow_max = c->tune.follow_max > 0 ? c->tune.follow_max : misti::FOLLOW_MAX_CHAINS;
+        int64_t follow_max = c->tune.follow_max > 0 ? c->tune.follow_max : misti::FOLLOW_MAX_CHAINS;
+        // mid-sized batches: one chain per wave is the latency shape (a 1 024-chain batch then occupies every wave slot of the chip);
+        // when other contexts have batches in flight the caller is after throughput and the packed shape carries ten chains per
+        // instruction stream (up to 1.9 x the rate).  Looked at only where it matters; the result never depends on it.
+        const int busy_from = c->tune.busy_contexts >= 0 ? c->tune.busy_contexts : misti::FOLLOW_BUSY_CONTEXTS;
+        if (c->tune.follow_max <= 0 && busy_from > 0 && est > misti::FOLLOW_BUSY_CHAINS && est <= follow_max && other_contexts_busy(c) >= busy_from)
+            follow_max = misti::FOLLOW_BUSY_CHAINS;
         cpw = (est >= 0 && est <= follow_max) ? 1 : misti::correct_cands_per_wave(n_cand, c->tune);
         const int f = c->tune.chains_per_wave;                       // diagnostic override (scratch experiments, tests)
         if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10) cpw = f;
@@ -369,6 +391,11 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         HIP_TRY_EV(misti::launch_llk(n_cand, d_jafs, d_status, n_rep, d_jsfs, d_consts, d_llk, c->unfolded, c->stream), a, b);
         if (int r = record_end(c, 2, a, b)) return r;
         if (c->timing) c->launches[2] += 1;
+    }
+    if (c->last_ev) {                              // behind the batch: other contexts read it (other_contexts_busy)
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        HIP_TRY(hipEventRecord(c->last_ev, c->stream));
+        c->last_ev_set = true;
     }
     return 0;
 }
@@ -524,6 +551,11 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
     } catch (const std::exception& e) {
         return fail(MISTI_E_ARG, "misti_create: %s", e.what());
     }
+    if (hipEventCreateWithFlags(&c->last_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->last_ev = nullptr; }
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        g_ctxs.push_back(c);
+    }
     guard.keep = true;
     *out = c;
     return 0;
@@ -531,12 +563,17 @@ int misti_create(const misti_model_t* model, int device, misti_ctx** out) {
 
 int misti_destroy(misti_ctx* c) {
     if (!c) return 0;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + (long)i); break; }
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->ws_solver, &c->ws_iters, &c->ws_post,
                     &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
         b->release();
     if (c->order_ev) (void)hipEventDestroy(c->order_ev);
+    if (c->last_ev) (void)hipEventDestroy(c->last_ev);
     c->pin_in.release();
     c->pin_out.release();
     c->nm_f64.release();

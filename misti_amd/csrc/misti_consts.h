@@ -20,6 +20,11 @@ constexpr int FOLLOW_MAX_CHAINS = 1024; // up to this many chains a batch runs o
                                         // workgroups are resident at 2 waves per SIMD: one round.  Measured (MI355X): 1 024 chains 1.68 ms
                                         // against 2.71 ms packed; 2 048 chains (config 5) 5.07 against 5.50 ms alone, and with 20 batches in
                                         // flight 1.7e7 against 4.1e7 evals/s - a packed wave carries ten chains per instruction stream
+constexpr int FOLLOW_BUSY_CHAINS = 128; // ... but only up to this many while the device is busy with OTHER contexts' batches (FOLLOW_BUSY_CONTEXTS of them or
+                                        // more have a batch in flight): one chain per wave buys latency with the whole chip, and a caller who
+                                        // overlaps batches wants throughput.  Measured, 20 batches in flight: 128 chains 3.3e7 evals/s either way;
+                                        // 256 chains 3.7e7 one per wave, 4.7e7 packed; 512: 4.0e7 / 6.3e7; 1 024 (config2x16): 4.2e7 / 7.7e7
+constexpr int FOLLOW_BUSY_CONTEXTS = 3;
 constexpr int FOLLOW_MIN_BLOCKS = 256;   // workgroups of the one-chain-per-wave launch whatever the (possibly stale) chain-count hint says
 constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
 }  // namespace misti

@@ -182,6 +182,8 @@ struct Tuning {
     bool no_trunk = false;     // MISTI_NO_TRUNK=1: every candidate walks all its intervals
     int follow_max = 0;        // MISTI_FOLLOW_MAX_CHAINS: chains up to which a batch runs one chain per wave (0: FOLLOW_MAX_CHAINS)
     int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
+    int busy_contexts = -1;    // MISTI_FOLLOW_BUSY_CONTEXTS: other contexts with a batch in flight from which on a batch of more than
+                               // FOLLOW_BUSY_CHAINS chains is packed (-1: FOLLOW_BUSY_CONTEXTS; 0: never look, always the latency shape)
 };
 Tuning read_tuning();
 int64_t trunk_capacity(int64_t n_cand, const Tuning& tn);

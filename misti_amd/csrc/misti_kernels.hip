@@ -2704,6 +2704,7 @@ Tuning read_tuning() {
     t.no_trunk = flag("MISTI_NO_TRUNK");
     t.follow_max = num("MISTI_FOLLOW_MAX_CHAINS");
     t.min_blocks = num("MISTI_FOLLOW_MIN_BLOCKS");
+    t.busy_contexts = getenv("MISTI_FOLLOW_BUSY_CONTEXTS") ? num("MISTI_FOLLOW_BUSY_CONTEXTS") : -1;
     return t;
 }
 

@@ -151,4 +151,5 @@ def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true
     return w
 
 
-BUILDERS = {"config1": config1, "config2": config2, "config2x16": config2x16, "config3": config3, "config4": config4, "config5": config5}
+BUILDERS = {"config1": config1, "config2": config2, "config2x16": config2x16, "config2x2": lambda f: config2x16(f, n_grid=2),
+            "config2x4": lambda f: config2x16(f, n_grid=4), "config2x8": lambda f: config2x16(f, n_grid=8), "config3": config3, "config4": config4, "config5": config5}

@@ -136,3 +136,53 @@ def test_shard_indices_partition():
                 parts = [shard_indices(n, r, w, il) for r in range(w)]
                 allidx = np.sort(np.concatenate(parts)) if parts else np.array([])
                 assert np.array_equal(allidx, np.arange(n))
+
+
+def _worker_chain(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from misti_amd.dist import chain_shards, evaluate_sharded
+    split, params, jsfs = tiny_grid()[4:]
+    eng = OracleEngine()
+    out = evaluate_sharded(eng.evaluate, split, params, jsfs, by_chain=True)
+    mine = chain_shards(params, len(split), world)[rank]
+    q.put((rank, out.numpy(), eng.chains_seen, len(mine)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharding_by_chain_keeps_chains_whole_and_changes_no_value(world):
+    """`by_chain=True`: whole chains (identical parameter vectors) are dealt to the ranks - the grid's 3 chains of 4 splits each
+    land on distinct ranks, none is computed twice - and the gathered table equals the unsharded evaluation bit for bit."""
+    split, params, jsfs = tiny_grid()[4:]
+    want = OracleEngine().evaluate(split, params, jsfs).llk
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_chain, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sum(chains for _, _, chains, _ in res) == 3                            # every chain on exactly one rank
+    assert sum(n for _, _, _, n in res) == len(split)
+    for rank, got, chains, n_mine in res:
+        assert np.array_equal(got, want), rank
+        assert n_mine == 4 * chains                                               # all four splits of a chain travel with it
+
+
+def test_chain_shards_partition_and_balance():
+    from misti_amd.dist import chain_shards
+    rng = np.random.default_rng(1)
+    rates = rng.random((37, 2))
+    params = np.repeat(rates, 5, axis=0)[rng.permutation(37 * 5)]                 # 37 chains x 5 members, shuffled
+    for world in (1, 2, 3, 8):
+        sh = chain_shards(params, len(params), world)
+        assert np.array_equal(np.sort(np.concatenate(sh)), np.arange(len(params)))
+        for s in sh:                                                               # a chain never spans ranks
+            keys = {tuple(params[i]) for i in s}
+            assert len(s) == 5 * len(keys)
+        assert max(len(s) for s in sh) - min(len(s) for s in sh) <= 5
+    assert [len(s) for s in chain_shards(None, 10, 3)] == [4, 3, 3]

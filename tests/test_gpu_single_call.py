@@ -86,3 +86,22 @@ def test_config5_shape_follows_with_more_chains_than_resident_workgroups():
     assert np.array_equal(a.status, b.status)
     assert np.array_equal(a.llk, b.llk, equal_nan=True)
     assert np.array_equal(a.jafs, b.jafs, equal_nan=True)
+
+
+def test_busy_device_changes_the_launch_shape_not_the_results():
+    """A 256-chain batch runs one chain per wave when the device is idle and packed ten per wave when three or more other
+    contexts have batches in flight (misti_consts.h: FOLLOW_BUSY_*): 12 batches overlapped on 6 lanes against the same batch
+    evaluated alone - every value bit for bit the same."""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    from misti_amd.lanes import LanePool
+    w = workloads.config2x16(lambda *a: truth_spectrum(*a), n_grid=4)
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        e.evaluate(w.split_time, w.params, w.jsfs)
+        alone = e.evaluate(w.split_time, w.params, w.jsfs)
+    with LanePool(w.times, w.lh, lanes=6, **w.engine_kwargs()) as pool:
+        pool.map([(w.split_time, w.params, w.jsfs)] * 6)                      # every lane learns its chain count
+        out = pool.map([(w.split_time, w.params, w.jsfs)] * 12)
+    for llk, jafs, status in out:
+        assert np.array_equal(status, alone.status)
+        assert np.array_equal(llk, alone.llk, equal_nan=True) and np.array_equal(jafs, alone.jafs, equal_nan=True)
