@@ -874,8 +874,8 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
             // speculative iteration: every point SciPy could ask for, one batch, one decision kernel
             HIP_TRY(misti::launch_nm_spec_points(st, bound, sm));
             if (int r = run_dev(c, bound * K, st.ps_split, st.ps, nullptr, 1, w.d_row, w.llk_spec, nullptr, nullptr, nullptr, nullptr)) return r;
-            HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
-            HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
+            // (no memsets here: nm_spec_points_kernel zeroed the next slot counter, and the reflection-split array is only read by the
+            //  three-batch path, which a search never returns to - the number of live starts only falls)
             HIP_TRY(misti::launch_nm_spec_finish(st, bound, w.llk_spec, sm));
             ++spec_iters;
         } else {

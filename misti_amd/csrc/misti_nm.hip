@@ -232,6 +232,7 @@ void nm_finish_kernel(NmState st, int64_t bound, const double* __restrict__ llk3
 __global__ __launch_bounds__(256)
 void nm_spec_points_kernel(NmState st, int64_t bound) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) st.count_next[0] = 0;          // the slot counter nm_spec_finish_kernel fills (later in stream order): no memset launch for it
     if (i >= bound) return;
     const int N = st.N, V = N + 1, K = 4 + N;
     double* pt = st.ps + i * (int64_t)K * N;
