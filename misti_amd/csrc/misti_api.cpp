@@ -266,7 +266,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
     // chain tables: TWO sets {n_chains[2], table, slot_chain, slot_len} used alternately - a batch clears the other set for its successor
     const size_t set_n = 4 + 4 * tsize;                     // counters [4] | table | slot_chain | slot_len | slot_keep
-    const size_t i32_n = 2 * set_n + 8 * nc + ntr;          // two table sets | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status, chain_order | trunk_ok
+    const size_t i32_n = 2 * set_n + 10 * nc + ntr;         // two table sets | slot_of, of, chain_slot, rep, fail_t, fail_status, tail_status, chain_order, resume_t, resume_list | trunk_ok
     HIP_TRY(c->ws_chain_f64.reserve(f64_n * sizeof(double)));
     {
         void* before = c->ws_chain_i32.p;
@@ -296,7 +296,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.slot_keep = cb.slot_len + tsize;
         cb.z_n_chains = set[cur ^ 1]; cb.z_table = set[cur ^ 1] + 4; cb.z_slot_len = cb.z_table + 2 * tsize; cb.z_slot_keep = cb.z_slot_len + tsize;
         cb.slot_of = q; q += nc; cb.of = q; q += nc; cb.chain_slot = q; q += nc; cb.rep = q; q += nc;
-        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc; cb.chain_order = q; q += nc;
+        cb.fail_t = q; q += nc; cb.fail_status = q; q += nc; cb.tail_status = q; q += nc; cb.chain_order = q; q += nc; cb.resume_t = q; q += nc; cb.resume_list = q; q += nc;
         cb.trunk_ok = q;
         cb.tmask = (uint32_t)(tsize - 1);
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
@@ -345,13 +345,15 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // chains per wavefront: packed (up to 8) when the batch is large - fewer instructions in total, which is what
     // counts when batches overlap - unless it is known to collapse into a few long chains (pure latency: one chain
     // per wave and the trunk following it)
+    int busy_seen = -1;                                      // other contexts with a batch in flight (looked up at most once per batch)
+    auto busy = [&]() { if (busy_seen < 0) busy_seen = other_contexts_busy(c); return busy_seen; };
     auto shape = [&](int64_t est, int& cpw, bool& follow) {
         int64_t follow_max = c->tune.follow_max > 0 ? c->tune.follow_max : misti::FOLLOW_MAX_CHAINS;
         // mid-sized batches: one chain per wave is the latency shape (a 1 024-chain batch then occupies every wave slot of the chip);
         // when other contexts have batches in flight the caller is after throughput and the packed shape carries ten chains per
         // instruction stream (up to 1.9 x the rate).  Looked at only where it matters; the result never depends on it.
         const int busy_from = c->tune.busy_contexts >= 0 ? c->tune.busy_contexts : misti::FOLLOW_BUSY_CONTEXTS;
-        if (c->tune.follow_max <= 0 && busy_from > 0 && est > misti::FOLLOW_BUSY_CHAINS && est <= follow_max && other_contexts_busy(c) >= busy_from)
+        if (c->tune.follow_max <= 0 && busy_from > 0 && est > misti::FOLLOW_BUSY_CHAINS && est <= follow_max && busy() >= busy_from)
             follow_max = misti::FOLLOW_BUSY_CHAINS;
         cpw = (est >= 0 && est <= follow_max) ? 1 : misti::correct_cands_per_wave(n_cand, c->tune);
         const int f = c->tune.chains_per_wave;                       // diagnostic override (scratch experiments, tests)
@@ -376,7 +378,15 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     int cpw_chains = 1;
     bool follow = false;
     shape(est_chains, cpw_chains, follow);
-    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, c->stream), a, b);
+    // Packed launches let a chain whose solve runs away yield to a second launch, one chain per wave (latency: a packed launch ends
+    // with its few long chains) - unless other contexts keep the device busy, where the packed shape's throughput is what counts.
+    int yield_nfev = 0;
+    if (cpw_chains > 1) {
+        yield_nfev = c->tune.yield_nfev >= 0 ? c->tune.yield_nfev : misti::YIELD_NFEV;
+        const int busy_from = c->tune.busy_contexts >= 0 ? c->tune.busy_contexts : misti::FOLLOW_BUSY_CONTEXTS;
+        if (yield_nfev > 0 && busy_from > 0 && busy() >= busy_from) yield_nfev = 0;
+    }
+    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, yield_nfev, c->stream), a, b);
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));

@@ -59,6 +59,8 @@ struct ChainBufs {
     int32_t* slot_len;      // [tsize] slot -> number of full intervals needed (max over members)
     int32_t* slot_keep;     // [tsize] slot -> numT - (first interval at which a member leaves the trunk), max over members: the trunk
                             //         stores its records from interval numT - slot_keep on (0: no member reads any)
+    int32_t* resume_t;      // [n] per chain that yielded in a packed launch: the interval it resumes at (correct_resume_kernel)
+    int32_t* resume_list;   // [n] those chains; length n_chains[3], head n_chains[2]
     int32_t* chain_order;   // [n] chains by descending length (the last candidate block of setup_kernel sorts them): dispatch order
     int32_t* slot_of;       // [n] candidate -> slot
     int32_t* of;            // [n] candidate -> chain, resolved by the idle blocks of the chain launch
@@ -182,6 +184,8 @@ struct Tuning {
     bool no_trunk = false;     // MISTI_NO_TRUNK=1: every candidate walks all its intervals
     int follow_max = 0;        // MISTI_FOLLOW_MAX_CHAINS: chains up to which a batch runs one chain per wave (0: FOLLOW_MAX_CHAINS)
     int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
+    int yield_nfev = -1;       // MISTI_YIELD_NFEV: evaluations after which a solve of a PACKED launch yields its chain to correct_resume_kernel
+                               // (-1: YIELD_NFEV; 0: never)
     int busy_contexts = -1;    // MISTI_FOLLOW_BUSY_CONTEXTS: other contexts with a batch in flight from which on a batch of more than
                                // FOLLOW_BUSY_CHAINS chains is packed (-1: FOLLOW_BUSY_CONTEXTS; 0: never look, always the latency shape)
 };
@@ -193,7 +197,7 @@ hipError_t launch_setup(const DevModel& m, int64_t n, const double* params, cons
 int correct_cands_per_wave(int64_t n_items, const Tuning& tn);
 bool trunk_follows(int cpw_chains, int64_t trunk_cap, const Tuning& tn);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, hipStream_t stream);
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
                            int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, const Tuning& tn, hipStream_t stream);

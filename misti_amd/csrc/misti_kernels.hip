@@ -1272,7 +1272,7 @@ template <bool CPFIT, int GROUP, bool TAIL, bool PRE = false>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
                   int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr,
-                  const int32_t* chain_map = nullptr) {
+                  const int32_t* chain_map = nullptr, int yield_nfev = 0, int t_start = 0) {
     const int lane = lane_id();
     const int sub = lane % GROUP;
     const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
@@ -1320,7 +1320,13 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         tr_w = cb.trace + slot * (int64_t)(m.numT + 1) * 6;
         ps.p[0][0] = 1; ps.p[0][1] = 0; ps.p[0][2] = 0;
         ps.p[1][0] = 0; ps.p[1][1] = 1; ps.p[1][2] = 0;
-        if (sub == 0) { tr_w[0] = 1; tr_w[1] = 0; tr_w[2] = 0; tr_w[3] = 1; tr_w[4] = 0; tr_w[5] = 0; }
+        if (t_start > 0) {
+            // a chain that YIELDED in the packed launch (see below) resumes at the interval it was in: the pair state before
+            // interval t_start is in its trace, and a solve restarted from the same state is the same solve
+            t = t_start;
+            const double* r = tr_w + 6 * t_start;
+            ps.p[0][0] = r[0]; ps.p[1][0] = r[1]; ps.p[0][1] = r[2]; ps.p[1][1] = r[3]; ps.p[0][2] = r[4]; ps.p[1][2] = r[5];
+        } else if (sub == 0) { tr_w[0] = 1; tr_w[1] = 0; tr_w[2] = 0; tr_w[3] = 1; tr_w[4] = 0; tr_w[5] = 0; }
     } else {
         status = setup_candidate(m, split_time[cand], par, G, bb);
         if (sub == 0) cb.tail_status[cand] = MISTI_OK;
@@ -1348,6 +1354,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     double cost = 0.0, Delta = 0.0, alpha = 0.0, predicted = 0.0;
     int nfev = 0;
     bool first = false, in_solve = false;
+    bool yielded = false;      // packed launch: this chain left at interval t for correct_resume_kernel
     bool noise_go = false;     // default fit: the solve went on past a gradient test its noise-free residual satisfied (ect_noise_continues)
     // speculative slots (one chain per wave only): SPEC_SLOTS x 6 lanes, slot 0 = the point the solver asked for
 #ifndef MISTI_SPEC
@@ -1489,6 +1496,12 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             if (uni<GROUP>(!in_solve)) { active = false; break; }  // reached the split, or failed
         }
         STAMP(c_adv)
+        // ---- yield (packed launches only) ----------------------------------------------------------------------------------
+        // A solve that has not converged after yield_nfev evaluations is a rate running away: tens to hundreds of evaluations,
+        // interval after interval, each of them alone in its six lanes - a packed launch ends with its few such chains (16 384
+        // random starts: 9 % of the chains, 3 x the mean evaluation count; the average wave lives a third of the kernel).  The chain
+        // leaves here and is RESUMED at this interval, one chain per wave with the speculation tree, by correct_resume_kernel.
+        if (!TAIL && yield_nfev > 0 && in_solve && !first && nfev >= yield_nfev) { yielded = true; active = false; break; }
         // ---- one residual batch: the point the solver needs in slot 0, guesses of its successors in the other slots ----
         // One chain per wave leaves 58 of 64 lanes idle during an evaluation.  In the exact rank-one regime (a rate
         // decoupled after a runaway: its Jacobian column is exactly zero and the solver moves along the other axis by
@@ -1736,12 +1749,19 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         if (uni<GROUP>(stop)) break;
         STAMP(c_book)
     }
-    if (dg.guard) { status = MISTI_NUMERIC; if (!TAIL) t = 0; }       // an overflowing iterate was cut off somewhere
+    if (dg.guard) { status = MISTI_NUMERIC; if (!TAIL) t = 0; yielded = false; }       // an overflowing iterate was cut off somewhere
     if (sub == 0) {
         if (!TAIL) {
-            cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
-            cb.fail_status[slot] = status;
             double* r = cb.work + slot * 6;
+            if (yielded) {
+                cb.resume_t[slot] = t;
+                cb.resume_list[atomicAdd(&cb.n_chains[3], 1)] = (int32_t)slot;
+            } else {
+                cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
+                cb.fail_status[slot] = status;
+            }
+            if (t_start > 0) { dg.evals += (int)r[0]; dg.dense += (int)r[1]; dg.terms += (int)r[2]; dg.spec += (int)r[3]; dg.lm += (int)r[5];
+                               dg.max_nfev = dg.max_nfev > (int)r[4] ? dg.max_nfev : (int)r[4]; }     // counters of the part before the yield
             r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.spec; r[4] = dg.max_nfev; r[5] = dg.lm;
 #ifdef MISTI_STAMP
             r[0] = (double)c_tree; r[1] = (double)(c_collect + c_update); r[2] = (double)c_next;
@@ -1756,16 +1776,42 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
 #ifndef MISTI_DEFAULT_FIT_WAVES
 #define MISTI_DEFAULT_FIT_WAVES 1
 #endif
+#ifndef MISTI_FOLLOW_WAVES
+#define MISTI_FOLLOW_WAVES 2
+#endif
 template <bool CPFIT, int GROUP>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPFIT ? 2 : MISTI_DEFAULT_FIT_WAVES, CPFIT ? 2 : MISTI_DEFAULT_FIT_WAVES)))
-void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+void correct_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params, int yield_nfev) {
     extern __shared__ double lds[];
     {   // candidate -> chain, once, by blocks that mostly have nothing else to do (the launch has one block per
         // 64/GROUP candidates, the chains occupy the first few): later kernels read it without the slot indirection
         const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
         if (i < n_items) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
     }
-    correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, nullptr, nullptr, nullptr, cb.chain_order);
+    correct_body<CPFIT, GROUP, false>(m, n_items, cb, split_time, params, (int64_t)blockIdx.x, lds, nullptr, nullptr, nullptr, cb.chain_order,
+                                      GROUP == 64 ? 0 : yield_nfev);
+}
+
+// The chains that yielded in a packed launch, one per wave (speculation tree, per-interval constants in LDS), pulled from the
+// list the packed launch left; workgroups beyond its length leave at once.  LDS: grid staging [3 numT] | constants [6 numT].
+template <bool CPFIT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CPFIT ? MISTI_FOLLOW_WAVES : 1, CPFIT ? MISTI_FOLLOW_WAVES : 1)))
+void correct_resume_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
+    extern __shared__ double lds[];
+    __shared__ int next;
+    const int n_res = cb.n_chains[3];
+    if ((int)blockIdx.x >= n_res) return;
+    double* pre = lds + 3 * (size_t)m.numT;
+    for (;;) {
+        if (threadIdx.x == 0) next = atomicAdd(&cb.n_chains[2], 1);
+        __syncthreads();
+        const int pos = next;
+        __syncthreads();
+        if (pos >= n_res) break;
+        const int64_t ch = cb.resume_list[pos];
+        correct_body<CPFIT, 64, false, true>(m, n_items, cb, split_time, params, ch, lds, nullptr, nullptr, pre, nullptr, 0, cb.resume_t[ch]);
+        __syncthreads();
+    }
 }
 
 // ---- replicate epilogue pieces ----
@@ -2109,9 +2155,6 @@ void trunk_follow(const DevModel& m, int64_t n_cand, const double* __restrict__ 
 // 1.884 -> 1.888 ms) and with 20 batches in flight the chip holds twice as many chains (2.38e7 -> 2.62e7 evals/s).
 // The register allocator gives up the 12 AGPRs for 28 bytes of scratch.  The default fit (256 VGPRs + 108 AGPRs) stays
 // at one wave.
-#ifndef MISTI_FOLLOW_WAVES
-#define MISTI_FOLLOW_WAVES 2
-#endif
 template <bool CPFIT>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CPFIT ? MISTI_FOLLOW_WAVES : 1, CPFIT ? MISTI_FOLLOW_WAVES : 1)))
 void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const double* __restrict__ split_time, const double* __restrict__ params) {
@@ -2705,6 +2748,7 @@ Tuning read_tuning() {
     t.follow_max = num("MISTI_FOLLOW_MAX_CHAINS");
     t.min_blocks = num("MISTI_FOLLOW_MIN_BLOCKS");
     t.busy_contexts = getenv("MISTI_FOLLOW_BUSY_CONTEXTS") ? num("MISTI_FOLLOW_BUSY_CONTEXTS") : -1;
+    t.yield_nfev = getenv("MISTI_YIELD_NFEV") ? num("MISTI_YIELD_NFEV") : -1;
     return t;
 }
 
@@ -2712,10 +2756,19 @@ static size_t correct_lds_bytes(int numT) { return (size_t)(3 * numT - 1) * size
 static size_t trunk_lds_bytes(int numT) { return (128 + 2 * (size_t)(numT + 1)) * sizeof(double); }
 
 template <bool CPFIT, int GROUP>
-static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, hipStream_t stream) {
+static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, int yield_nfev,
+                            hipStream_t stream) {
     const int per_wave = 64 / GROUP;
     dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
-    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params);
+    hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params, yield_nfev);
+    if (yield_nfev > 0 && GROUP != 64) {
+        // the chains that yielded, one per wave: as many workgroups as are resident (two waves per SIMD for --cpfit, one for the
+        // default fit); those beyond the list's length leave at once
+        const int64_t resident = CPFIT ? 2048 : 1024;
+        const int64_t blocks = n_items < resident ? n_items : resident;
+        const size_t lds = (9 * (size_t)m.numT) * sizeof(double);
+        hipLaunchKernelGGL((correct_resume_kernel<CPFIT>), dim3((unsigned)blocks), dim3(64), lds, stream, m, n_items, cb, split, params);
+    }
 }
 
 // One chain per wavefront and a trunk to build: the trunk follows its chain inside the chain launch
@@ -2747,7 +2800,7 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 // cpw: chains per wavefront, chosen by the caller from the expected number of chains
 // est_chains: chains of the previous batch of this size on the context, or < 0 when unknown
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, hipStream_t stream) {
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     if (follow) {
@@ -2766,7 +2819,7 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
         else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
         return hipGetLastError();
     }
-    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, stream)
+    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, yield_nfev, stream)
     return hipGetLastError();
 }
 

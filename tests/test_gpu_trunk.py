@@ -174,19 +174,24 @@ def test_speculation_and_reduction_do_not_change_results():
     from misti_amd.engine import Engine, truth_spectrum
     w = workloads.config2(lambda *a: truth_spectrum(*a))
     out = {}
-    for cpw in ("1", "4", "10"):
-        os.environ["MISTI_CHAINS_PER_WAVE"] = cpw
+    # "10y": packed, and a chain whose solve runs away YIELDS after 8 evaluations and is resumed one per wave (correct_resume_kernel)
+    for cpw, env in (("1", {}), ("4", {"MISTI_YIELD_NFEV": "0"}), ("10", {"MISTI_YIELD_NFEV": "0"}), ("10y", {})):
+        os.environ["MISTI_CHAINS_PER_WAVE"] = cpw.rstrip("y")
+        os.environ.update(env)
         try:
             with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
                 e.evaluate(w.split_time, w.params, w.jsfs)                 # the launch shape follows the previous batch's chain count
                 out[cpw] = e.evaluate(w.split_time, w.params, w.jsfs, want_lc=True, want_pr=True)
         finally:
             os.environ.pop("MISTI_CHAINS_PER_WAVE", None)
+            for k in env:
+                os.environ.pop(k, None)
     a = out["1"]
     assert (a.status == 0).all()
     spec = a.pr[:, -1, 3]                                                   # work counters: solver steps taken from speculative slots
     assert spec.max() > 100 and (out["10"].pr[:, -1, 3] == 0).all()         # the first really speculated, the packed one did not
-    for cpw in ("4", "10"):
+    assert out["10y"].pr[:, -1, 3].max() > 100                              # ... and the chains that yielded did, after their resumption
+    for cpw in ("4", "10", "10y"):
         b = out[cpw]
         assert np.array_equal(a.status, b.status)
         for name in ("llk", "jafs", "lc"):
