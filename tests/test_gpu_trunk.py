@@ -198,3 +198,34 @@ def test_speculation_and_reduction_do_not_change_results():
             x, y = getattr(a, name), getattr(b, name)
             assert np.array_equal(x, y, equal_nan=True), (cpw, name, float(np.nanmax(np.abs(x - y))))
         assert np.array_equal(a.pr[:, :-1, :], b.pr[:, :-1, :], equal_nan=True), cpw   # pair-state trace (last row: counters)
+
+
+def test_default_fit_yield_is_off_by_default_and_bit_identical_when_forced():
+    """The default fit does not yield by default (its one-per-wave kernel holds one wave per SIMD; measured slower, DESIGN.md
+    section 4) but MISTI_YIELD_NFEV can force it: random two-band starts through the packed default-fit kernel with and without
+    yielding, and the --cpfit build of the same starts with its default (yielding) - the same bits either way."""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = workloads.config3(lambda *a: truth_spectrum(*a), n_start=3000)
+    out = {}
+    for fit, name, env in ((False, "default", {}), (False, "default, forced", {"MISTI_YIELD_NFEV": "8"}),
+                           (True, "cpfit", {}), (True, "cpfit, never", {"MISTI_YIELD_NFEV": "0"})):
+        kw = w.engine_kwargs()
+        kw["cpfit"] = fit
+        os.environ["MISTI_CANDS_PER_WAVE"] = "10"
+        os.environ.update(env)
+        try:
+            with Engine(w.times, w.lh, **kw) as e:
+                out[name] = e.evaluate(w.split_time, w.params, w.jsfs, want_lc=True, want_pr=True)
+        finally:
+            os.environ.pop("MISTI_CANDS_PER_WAVE", None)
+            for k in env:
+                os.environ.pop(k, None)
+    assert (out["default"].pr[:, -1, 3] == 0).all()                     # nothing speculated: nothing yielded
+    assert out["default"].pr[:, -1, 4].max() >= 8                       # ... though some solves are long enough to yield when forced
+    assert out["cpfit"].pr[:, -1, 3].max() > 0 and (out["cpfit, never"].pr[:, -1, 3] == 0).all()
+    for a, b in (("default", "default, forced"), ("cpfit", "cpfit, never")):
+        assert np.array_equal(out[a].status, out[b].status)
+        for name in ("llk", "jafs", "lc"):
+            assert np.array_equal(getattr(out[a], name), getattr(out[b], name), equal_nan=True), (a, name)
+        assert np.array_equal(out[a].pr[:, :-1, :], out[b].pr[:, :-1, :], equal_nan=True), a

@@ -64,8 +64,13 @@ def pmc_last(src_dir):
 
 
 WORKLOADS = ("config2", "config2x16", "config3", "config5")
-KERNEL1 = {"config2": "misti::correct_follow_kernel", "config2x16": "misti::correct_follow_kernel",
-           "config3": "misti::correct_kernel<true, 6>", "config5": "misti::correct_kernel<true, 6>"}
+# kernel 1 of a workload; a packed launch is TWO kernels (the packed phase and the chains that yielded, resumed one per wave):
+# their counters are added
+KERNEL1 = {"config2": ("misti::correct_follow_kernel",), "config2x16": ("misti::correct_follow_kernel",),
+           "config3": ("misti::correct_kernel<true, 6>", "misti::correct_resume_kernel"),
+           "config5": ("misti::correct_kernel<true, 6>", "misti::correct_resume_kernel")}
+SQ = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+      "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY")
 
 
 def main():
@@ -105,21 +110,27 @@ def main():
                 "SQ_ACTIVE_INST_* count quad-cycles, SQ_INSTS_* instructions per wave." % wl)
         json.dump({"note": note, "workload": wl, "counters": counters}, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
         entry = {"source": "profiles/%s_pmc_%s.json" % (tag, wl)}
-        for key, pat in (("correct", KERNEL1[wl]), ("post", "misti::post_kernel"), ("spectrum", "misti::spectrum_kernel<true>")):
-            for k, d in counters.items():
-                if not k.startswith(pat):
-                    continue
-                if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-                    entry[key + "_hbm_bytes_per_launch"] = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
-                if "SQ_INSTS_VALU" in d:
-                    v = {c: d[c] for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
-                                           "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY") if c in d}
-                    if d.get("SQ_THREAD_CYCLES_VALU") and d.get("SQ_ACTIVE_INST_VALU"):
-                        # mean share of the 64 lanes a VALU instruction had live.  Both counters tick once per 4-cycle issue (the spectrum
-                        # kernel, 44 live lanes of 64 in its main loop and fewer around it, reads 0.51)
-                        v["lane_occupancy"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64.0)
-                    v["kernel"] = k
-                    entry[key + "_valu"] = v
+        for key, pats in (("correct", KERNEL1[wl]), ("post", ("misti::post_kernel",)), ("spectrum", ("misti::spectrum_kernel<true>",))):
+            hbm, v, names = 0.0, {}, []
+            for pat in pats:
+                for k, d in counters.items():
+                    if not k.startswith(pat):
+                        continue
+                    names.append(k)
+                    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+                        hbm += (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+                    for c in SQ:
+                        if c in d:
+                            v[c] = v.get(c, 0.0) + d[c]
+            if hbm:
+                entry[key + "_hbm_bytes_per_launch"] = hbm
+            if "SQ_INSTS_VALU" in v:
+                if v.get("SQ_THREAD_CYCLES_VALU") and v.get("SQ_ACTIVE_INST_VALU"):
+                    # mean share of the 64 lanes a VALU instruction had live.  Both counters tick once per 4-cycle issue (the spectrum
+                    # kernel, 44 live lanes of 64 in its main loop and fewer around it, reads 0.51)
+                    v["lane_occupancy"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0)
+                v["kernel"] = " + ".join(names)
+                entry[key + "_valu"] = v
         latest["workloads"][wl] = entry
         print("wrote %s_pmc_%s.json:" % (tag, wl), {k: v for k, v in entry.items() if k.endswith("per_launch")})
     if latest["workloads"]:
