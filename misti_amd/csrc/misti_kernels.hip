@@ -1347,6 +1347,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     const bool correct = !(m.flags & MISTI_TRUE_EPS);
     const int max_nfev = 200;                    // 100 * n (least_squares.py)
     Diag dg;
+#ifdef MISTI_TREE_STATS
+    int ts_tree = 0, ts_miss = 0, ts_cons = 0, ts_miss_at[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     // solver state of the interval in progress
     PairProblem pb;
@@ -1616,9 +1619,15 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 else if (cur == 2) child = code == 3 ? 5 : -1;
                 else if (cur == 3) child = code == 1 ? 6 : code == 2 ? 7 : 8;
                 else if (cur == 6) child = code == 3 ? 9 : -1;
+#ifdef MISTI_TREE_STATS
+                if (child < 0) { ts_miss += 1; ts_miss_at[cur == 1 || cur == 2 ? 0 : cur == 4 || cur == 5 ? 1 : cur == 7 ? 2 : cur == 8 ? 3 : cur == 9 ? 4 : 5] += 1; }
+#endif
                 if (child < 0) break;
                 cur = child;
             }
+#ifdef MISTI_TREE_STATS
+            ts_tree += 1; ts_cons += consumed;
+#endif
             if (consumed > 0) {
                 const int at = 6 * last;
                 x[0] = bcast(xs[0], at); x[1] = bcast(xs[1], at);
@@ -1763,6 +1772,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
             if (t_start > 0) { dg.evals += (int)r[0]; dg.dense += (int)r[1]; dg.terms += (int)r[2]; dg.spec += (int)r[3]; dg.lm += (int)r[5];
                                dg.max_nfev = dg.max_nfev > (int)r[4] ? dg.max_nfev : (int)r[4]; }     // counters of the part before the yield
             r[0] = dg.evals; r[1] = dg.dense; r[2] = dg.terms; r[3] = dg.spec; r[4] = dg.max_nfev; r[5] = dg.lm;
+#ifdef MISTI_TREE_STATS
+            r[1] = ts_tree; r[2] = ts_miss; r[3] = ts_cons; r[4] = ts_miss_at[0] * 1e6 + ts_miss_at[1] * 1e3 + ts_miss_at[2]; r[5] = ts_miss_at[3] * 1e6 + ts_miss_at[4] * 1e3 + ts_miss_at[5];
+#endif
 #ifdef MISTI_STAMP
             r[0] = (double)c_tree; r[1] = (double)(c_collect + c_update); r[2] = (double)c_next;
             r[3] = (double)c_adv; r[4] = (double)c_batch; r[5] = (double)c_book;
