@@ -709,7 +709,7 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
     wave-instructions issued x 4 cycles against 1 024 SIMDs x clock), `hbm` carries the figures the contract asks for
     (algorithmic bytes / HIP-event duration against 8 TB/s, counter traffic), `valu` the raw counters.  Durations are HIP events
     of this run; the counters are rocprofv3 --pmc passes of the same command, stored per workload in profiles/pmc_latest.json."""
-    traffic, traffic_source, valu = None, None, None
+    traffic, traffic_source, valu, second = None, None, None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc) and world == 1:
         try:
@@ -731,8 +731,18 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
                             "note": "frac = 4 x SQ_INSTS_VALU / (1 024 SIMDs x kernel cycles at 2.4 GHz): share of the chip's fp64 VALU issue slots this launch "
                                     "used; lane_occupancy = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes live per issued instruction (wave-uniform "
                                     "bookkeeping of a chain runs in all 64 lanes: live, not useful)"}
+                # the other big kernel of the batch (kernel 2 when the correction dominates): the same two figures
+                oth = "spectrum" if dom == "correct" else "correct"
+                vo = j.get(oth + "_valu")
+                if vo and vo.get("SQ_INSTS_VALU") and per_ms.get(oth, 0) > 0:
+                    cyc = per_ms[oth] * 1e-3 * GPU_CLOCK_HZ
+                    second = {"kernel": vo.get("kernel"), "ms_per_launch": per_ms[oth], "wave_insts": vo["SQ_INSTS_VALU"],
+                              "valu_frac": 4.0 * vo["SQ_INSTS_VALU"] / (N_SIMD * cyc), "lane_occupancy": vo.get("lane_occupancy"),
+                              "hbm_traffic_bytes": j.get(oth + "_hbm_bytes_per_launch"),
+                              "hbm_frac": (j.get(oth + "_hbm_bytes_per_launch") or 0.0) / (per_ms[oth] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "the batch's other large kernel, same definitions (counter traffic / duration for hbm_frac)"}
         except Exception:
-            traffic, valu = None, None
+            traffic, valu, second = None, None, None
     hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
            "algorithmic_bytes_per_launch": ab[dom]}
     common = {"kernel": dom + "_kernel", "candidates_per_launch": n, "chains_per_launch": ab["n_chains"], "ms_per_launch": per_ms, "traffic": traffic,
@@ -749,6 +759,8 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
         blk = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "note": "no stored SQ counters for this workload: HBM figures only; the path is bound by fp64 VALU issue latency, not by HBM (SURVEY 8d)"}
     blk.update(common)
+    if second:
+        blk["second_kernel"] = second
     return blk
 
 
