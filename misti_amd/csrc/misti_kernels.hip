@@ -2427,18 +2427,40 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
         }
         KSTAMP(5)
         if (status == MISTI_OK) {
-            // two-population share of the spectrum: lanes 0..6 each sum one class
-            xbuf[lane] = live ? w_post : 0.0; lds_fence();
-            double jp = 0.0;
-            // weights as bit planes (same products, same order as a table walk; one 24-byte load per class)
-            unsigned long long b0 = 0, b1 = 0, b2 = 0;
-            if (lane < 7) { b0 = c_tab.jaf_bits[lane][0]; b1 = c_tab.jaf_bits[lane][1]; b2 = c_tab.jaf_bits[lane][2]; }
-            auto weight = [&](int i) { return (double)(int)(((b0 >> i) & 1) | (((b1 >> i) & 1) << 1) | (((b2 >> i) & 1) << 2)); };
-            if (lane < 7) for (int i = 0; i < NS2; ++i) jp += weight(i) * xbuf[i];
-            lds_fence();
-            xbuf[lane] = live ? w_pre : 0.0; lds_fence();
-            if (lane < 2) for (int i = 0; i < NS2; ++i) jp += weight(i) * xbuf[i];
-            lds_fence();
+            // two-population share of the spectrum: class c = sum over the states of weight_c(state) x occupation integral (w_post for
+            // every class, w_pre for the two classes only the ancient sample's pre-date part feeds).  Every state lane forms its
+            // seven products; the seven sums over the wave are taken together - halves of the wave swap half of the classes at
+            // each of the first three butterfly steps (8 -> 4 -> 2 -> 1 classes per lane), three plain steps finish: 7 shuffles for
+            // all classes instead of a 44-step loop on seven lanes (a sixth of this kernel's instructions on a shared grid), and a
+            // pairwise sum instead of a running one.  Lanes 8c .. 8c + 7 end up with class c.
+            double jp;
+            {
+                double a4[4], a2[2], z;
+                {
+                    double a[8];
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) {
+                        const double wg = (double)c_tab.jaf[c][lane];
+                        a[c] = live ? (c < 2 ? wg * w_post + wg * w_pre : wg * w_post) : 0.0;
+                    }
+                    a[7] = 0.0;
+                    const bool hi = lane & 32;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const double keep = hi ? a[c + 4] : a[c], give = hi ? a[c] : a[c + 4]; a4[c] = keep + __shfl_xor(give, 32, 64); }
+                }
+                {
+                    const bool hi = lane & 16;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) { const double keep = hi ? a4[c + 2] : a4[c], give = hi ? a4[c] : a4[c + 2]; a2[c] = keep + __shfl_xor(give, 16, 64); }
+                }
+                {
+                    const bool hi = lane & 8;
+                    const double keep = hi ? a2[1] : a2[0], give = hi ? a2[0] : a2[1];
+                    z = keep + __shfl_xor(give, 8, 64);
+                }
+                z += __shfl_xor(z, 4, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 1, 64);
+                jp = __shfl(z, 8 * (lane & 7), 64);                                   // lane c < 7: class c
+            }
             // CollapsePops (:518-528)
             xbuf[lane] = live ? x : 0.0; lds_fence();
             double c8 = 0.0;
@@ -2462,12 +2484,16 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                 double inc = tau;                      // inclusive prefix sum over the wave
                 for (int o = 1; o < 64; o <<= 1) { double u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
                 double S = carry + (inc - tau);
+                // e^-3S and e^-6S as powers of e^-S, expm1(-3 tau) and expm1(-6 tau) from a = expm1(-tau) by (1 + a)^3 - 1 = a (3 + a (3 + a))
+                // and (1 + b)^2 - 1 = b (2 + b): two transcendentals per interval instead of six, a few ulps each way
+                const double e1 = exp(-S), e3 = e1 * e1 * e1, e6 = e3 * e3;
                 if (t < last) {
-                    G1 += exp(-S) * (-expm1(-tau)) / lam;
-                    G3 += exp(-3 * S) * (-expm1(-3 * tau)) / (3 * lam);
-                    G6 += exp(-6 * S) * (-expm1(-6 * tau)) / (6 * lam);
+                    const double a1 = expm1(-tau), a3 = a1 * (3.0 + a1 * (3.0 + a1)), a6 = a3 * (2.0 + a3);
+                    G1 += e1 * (-a1) / lam;
+                    G3 += e3 * (-a3) / (3 * lam);
+                    G6 += e6 * (-a6) / (6 * lam);
                 } else if (t == last) {
-                    G1 += exp(-S) / lam; G3 += exp(-3 * S) / (3 * lam); G6 += exp(-6 * S) / (6 * lam);
+                    G1 += e1 / lam; G3 += e3 / (3 * lam); G6 += e6 / (6 * lam);
                 }
                 carry += bcast(inc, 63);
             }
