@@ -1936,6 +1936,8 @@ __device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevMode
         for (int k = 1; k < INV_TABLE - 1; ++k) {
             const double inv = inv_next;
             inv_next = c_inv[k + 1];
+            // (the four source states: an LDS write and four reads; the same gather through ds_bpermute was measured slower - config 3's
+            // kernel 2 1.27 -> 1.62 ms)
             xbuf[lane] = p;
             lds_fence();
             double r0 = xbuf[R.srcl[0]], r1 = xbuf[R.srcl[1]], r2 = xbuf[R.srcl[2]], r3 = xbuf[R.srcl[3]];
@@ -2486,18 +2488,29 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
                 double S = carry + (inc - tau);
                 // e^-3S and e^-6S as powers of e^-S, expm1(-3 tau) and expm1(-6 tau) from a = expm1(-tau) by (1 + a)^3 - 1 = a (3 + a (3 + a))
                 // and (1 + b)^2 - 1 = b (2 + b): two transcendentals per interval instead of six, a few ulps each way
+                // (one division per interval: 1 / lam, shared by the three sums)
                 const double e1 = exp(-S), e3 = e1 * e1 * e1, e6 = e3 * e3;
+                const double rl = 1.0 / lam, rl3 = rl * (1.0 / 3.0), rl6 = rl * (1.0 / 6.0);
                 if (t < last) {
                     const double a1 = expm1(-tau), a3 = a1 * (3.0 + a1 * (3.0 + a1)), a6 = a3 * (2.0 + a3);
-                    G1 += e1 * (-a1) / lam;
-                    G3 += e3 * (-a3) / (3 * lam);
-                    G6 += e6 * (-a6) / (6 * lam);
+                    G1 += e1 * (-a1) * rl;
+                    G3 += e3 * (-a3) * rl3;
+                    G6 += e6 * (-a6) * rl6;
                 } else if (t == last) {
-                    G1 += e1 / lam; G3 += e3 / (3 * lam); G6 += e6 / (6 * lam);
+                    G1 += e1 * rl; G3 += e3 * rl3; G6 += e6 * rl6;
                 }
                 carry += bcast(inc, 63);
             }
-            for (int o = 32; o > 0; o >>= 1) { G1 += __shfl_xor(G1, o, 64); G3 += __shfl_xor(G3, o, 64); G6 += __shfl_xor(G6, o, 64); }
+            {
+                // the three sums over the wave together (see the class sums above): 7 shuffles instead of 18; lanes 0-15 end up
+                // with G1, 16-31 with G3, 32-47 with G6
+                const bool h5 = lane & 32, h4 = lane & 16;
+                const double k0 = (h5 ? G6 : G1) + __shfl_xor(h5 ? G1 : G6, 32, 64);     // G1 | G6
+                const double k1 = (h5 ? 0.0 : G3) + __shfl_xor(h5 ? G3 : 0.0, 32, 64);    // G3 | 0
+                double z = (h4 ? k1 : k0) + __shfl_xor(h4 ? k0 : k1, 16, 64);             // lanes 0-15: G1, 16-31: G3, 32-47: G6, 48-63: 0
+                z += __shfl_xor(z, 8, 64); z += __shfl_xor(z, 4, 64); z += __shfl_xor(z, 2, 64); z += __shfl_xor(z, 1, 64);
+                G1 = bcast(z, 0); G3 = bcast(z, 16); G6 = bcast(z, 32);
+            }
             // coefficient vectors of the three exponentials (after the sums: they are not live across the loop)
             double x0 = P8[0];
             const double a3[3] = {1.0, 4.0, 1.0};
