@@ -44,6 +44,12 @@ namespace misti {
 
 __constant__ DevTables c_tab;
 __constant__ double c_inv[INV_TABLE];   // c_inv[k] = 1/k: series terms divide by k (an fp64 division costs ~40 instructions)
+// Terms of the uniformisation series as a function of q = (largest exit rate) x (interval length): the series stops after term K,
+// the first k with e^-q q^(k-1) / (k-1)! < 1e-19 and k > q.  c_qmax[K] = the largest q for which K terms suffice (increasing in K;
+// c_qmax[1] < 0: never one term), so K(q) = 1 + #{ j >= 1 : c_qmax[j] < q } - a compare, a ballot and a population count per 64
+// entries instead of a running bound, a conversion and two compares inside every term (twopop_interval).
+constexpr int QMAX_TABLE = 320;         // Q_SWITCH = 96 needs K <= 240
+__constant__ double c_qmax[QMAX_TABLE];
 
 // exp(M T) P0 and the occupation integral per interval, two methods:
 //  * q = (largest exit rate) x (interval length) <= Q_SWITCH: uniformisation series
@@ -1931,9 +1937,15 @@ __device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevMode
         const double eq = exp(-q);
         double p = eq * x, ii = 0.0;
         double accp = p, acci = 0.0;
-        double b = eq, bprev = 1.0;
+        // the number of terms from q alone (q is the same in every lane): see c_qmax
+        int K = 1;
+        for (int c = 0; c < QMAX_TABLE / 64; ++c) {
+            const unsigned long long below = __ballot(c_qmax[1 + 64 * c + lane] < q);
+            K += __popcll(below);
+            if (below != ~0ull) break;
+        }
         double inv_next = c_inv[1];
-        for (int k = 1; k < INV_TABLE - 1; ++k) {
+        for (int k = 1; k <= K; ++k) {
             const double inv = inv_next;
             inv_next = c_inv[k + 1];
             // (the four source states: an LDS write and four reads; the same gather through ds_bpermute was measured slower - config 3's
@@ -1946,9 +1958,6 @@ __device__ __forceinline__ int twopop_interval(const TwoPopRow& R, const DevMode
             ii = (T * p + q * ii) * inv;
             p = pn;
             accp += p; acci += ii;
-            bprev = b;
-            b *= q * inv;
-            if (bprev < 1e-19 && (double)k > q) break;
         }
         x = accp; wint = acci;
     } else {
@@ -2769,6 +2778,24 @@ hipError_t upload_tables(const DevTables& t) {
     for (int k = 1; k < INV_TABLE; ++k) inv[k] = 1.0 / (double)k;
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_inv), inv, sizeof inv);
     if (e != hipSuccess) return e;
+    {
+        // c_qmax[K]: the root in (0, K - 1) of e^-q q^(K-1) / (K-1)! = 1e-19 (the Poisson weight grows with q below its mode), by bisection
+        static double qmax[QMAX_TABLE];
+        qmax[0] = -1.0; qmax[1] = -1.0;
+        const long double tol = logl(1e-19L);
+        for (int K = 2; K < QMAX_TABLE; ++K) {
+            long double lo = 0.0L, hi = (long double)(K - 1);
+            for (int it = 0; it < 200; ++it) {
+                const long double mid = 0.5L * (lo + hi);
+                const long double lw = -mid + (long double)(K - 1) * logl(mid) - lgammal((long double)K);
+                if (lw < tol) lo = mid; else hi = mid;
+            }
+            qmax[K] = (double)lo;
+        }
+        qmax[QMAX_TABLE - 1] = 1e300;           // never reached: Q_SWITCH bounds q
+        e = hipMemcpyToSymbol(HIP_SYMBOL(c_qmax), qmax, sizeof qmax);
+        if (e != hipSuccess) return e;
+    }
     return hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(DevTables));
 }
 
