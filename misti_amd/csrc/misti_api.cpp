@@ -872,6 +872,7 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
     HIP_TRY(hipEventSynchronize(ev[0]));
     int64_t bound = live_host[0];
     int64_t issued = 0, slots = 0, spec_iters = 0;
+    bool spec_primed = false;
     const int64_t K = 4 + N;
     for (int it = 0; bound > 0 && it < maxiter; ++it) {
         const int slot = it & 1;
@@ -882,13 +883,18 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
         }
         st.idx_cur = w.idx[cur]; st.count_cur = cnt + cur;
         st.idx_next = w.idx[cur ^ 1]; st.count_next = cnt + (cur ^ 1);
-        if (bound <= st.spec_cap) {
-            // speculative iteration: every point SciPy could ask for, one batch, one decision kernel
-            HIP_TRY(misti::launch_nm_spec_points(st, bound, sm));
+        const bool spec = bound <= st.spec_cap;
+        if (spec) {
+            // speculative iteration: every point SciPy could ask for, one batch, one decision kernel - which also lays out the points
+            // of the NEXT iteration and drops the count of live starts into the host's pinned word (nm_spec_step_kernel: the live
+            // starts of a speculative iteration fit one workgroup); only the first speculative iteration launches a points kernel
+            if (!spec_primed) { HIP_TRY(misti::launch_nm_spec_points(st, bound, sm)); spec_primed = true; }
             if (int r = run_dev(c, bound * K, st.ps_split, st.ps, nullptr, 1, w.d_row, w.llk_spec, nullptr, nullptr, nullptr, nullptr)) return r;
-            // (no memsets here: nm_spec_points_kernel zeroed the next slot counter, and the reflection-split array is only read by the
+            // (no memsets here: the points step zeroes the next slot counter, and the reflection-split array is only read by the
             //  three-batch path, which a search never returns to - the number of live starts only falls)
-            HIP_TRY(misti::launch_nm_spec_finish(st, bound, w.llk_spec, sm));
+            misti::NmState nx = st;
+            nx.idx_cur = st.idx_next; nx.count_cur = st.count_next; nx.idx_next = w.idx[cur]; nx.count_next = cnt + cur;
+            HIP_TRY(misti::launch_nm_spec_step(st, nx, bound, w.llk_spec, (int32_t*)&live_host[slot], sm));
             ++spec_iters;
         } else {
             if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, w.d_row, w.llk1, nullptr, nullptr, nullptr, nullptr)) return r;
@@ -900,7 +906,7 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
             HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
             HIP_TRY(misti::launch_nm_finish(st, bound, w.llk3, sm));
         }
-        HIP_TRY(hipMemcpyAsync((void*)&live_host[slot], cnt + (cur ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost, sm));
+        if (!spec) HIP_TRY(hipMemcpyAsync((void*)&live_host[slot], cnt + (cur ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost, sm));
         HIP_TRY(hipEventRecord(ev[slot], sm));
         cur ^= 1;
         ++issued;

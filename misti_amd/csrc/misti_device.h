@@ -141,6 +141,7 @@ hipError_t launch_nm_accept(const NmState& st, int64_t bound, const double* llk2
 hipError_t launch_nm_finish(const NmState& st, int64_t bound, const double* llk3, hipStream_t stream);
 hipError_t launch_nm_result(const NmState& st, double* x, double* llh, int32_t* status, hipStream_t stream);
 hipError_t launch_nm_spec_points(const NmState& st, int64_t bound, hipStream_t stream);
+hipError_t launch_nm_spec_step(const NmState& st, const NmState& nx, int64_t bound, const double* llk, int32_t* live_host, hipStream_t stream);
 hipError_t launch_nm_spec_finish(const NmState& st, int64_t bound, const double* llk, hipStream_t stream);
 
 // Batched basin hopping (scipy.optimize.basinhopping with Nelder-Mead as the local minimiser; reference semantics
