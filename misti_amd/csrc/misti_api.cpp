@@ -248,8 +248,12 @@ int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
         if (e_ != hipSuccess) { (void)record_end(c, -1, a, b); return fail(MISTI_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } \
     } while (0)
 
+// hints (what an internal caller knows about its own batch; 0 from the ABI's entry points, whose split times live on the device):
+//   RUN_INTEGER_SPLITS  no split time has a fractional part (or is negative: an empty slot) - no tail for the post launch
+//   RUN_UNSHARED        every candidate has its own parameter vector: no trunk for a batch too large for one chain per wave
+enum : unsigned { RUN_INTEGER_SPLITS = 1u, RUN_UNSHARED = 2u };
 int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
-            double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status) {
+            double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, unsigned hints = 0) {
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
     if (!d_split) return fail(MISTI_E_ARG, "split_time is NULL");
@@ -262,7 +266,8 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     const size_t nc = (size_t)n_cand, numT = (size_t)c->dm.numT;
     // chain machinery: one allocation per type, carved below
     const size_t tsize = misti::chain_table_size(n_cand);
-    const size_t ntr = (size_t)misti::trunk_capacity(n_cand, c->tune);
+    const int64_t follow_max_h = c->tune.follow_max > 0 ? c->tune.follow_max : misti::FOLLOW_MAX_CHAINS;
+    const size_t ntr = ((hints & RUN_UNSHARED) && n_cand > follow_max_h) ? 0 : (size_t)misti::trunk_capacity(n_cand, c->tune);
     const size_t f64_n = nc * numT * 2 + nc * (numT + 1) * 6 + nc * 6 + nc * 2 + nc * 6;
     // chain tables: TWO sets {n_chains[2], table, slot_chain, slot_len} used alternately - a batch clears the other set for its successor
     const size_t set_n = 4 + 4 * tsize;                     // counters [4] | table | slot_chain | slot_len | slot_keep
@@ -395,7 +400,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     c->diag_n = n_cand;
     if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                      n_rep, d_jsfs, d_consts, d_llk, follow, c->tune, c->stream), a, b);
+                                      n_rep, d_jsfs, d_consts, d_llk, follow, (hints & RUN_INTEGER_SPLITS) && (follow || ntr == 0), c->tune, c->stream), a, b);
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {
@@ -850,11 +855,13 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
     const size_t S = (size_t)st.S, V = (size_t)N + 1;
     st.maxiter = maxiter; st.maxfun = maxfun; st.xatol = xatol; st.fatol = fatol; st.split = split_time;
     hipStream_t sm = c->stream;
+    // what the search knows about its own batches: one split time for every point (empty slots carry -1), distinct points
+    const unsigned nm_hints = (split_time == std::floor(split_time) ? RUN_INTEGER_SPLITS : 0u) | RUN_UNSHARED;
     int32_t* cnt = w.cnt;
     HIP_TRY(hipMemsetAsync(cnt, 0, 4 * sizeof(int32_t), sm));
     HIP_TRY(hipMemsetAsync(st.split1, 0xBF, S * sizeof(double), sm));          // all-0xBF bytes: a negative double = "no point in this slot"
     HIP_TRY(misti::launch_nm_init(st, w.d_starts, sm));
-    if (int r = run_dev(c, (int64_t)(S * V), st.split0, st.sim, nullptr, 1, w.d_row, w.llk0, nullptr, nullptr, nullptr, nullptr)) return r;
+    if (int r = run_dev(c, (int64_t)(S * V), st.split0, st.sim, nullptr, 1, w.d_row, w.llk0, nullptr, nullptr, nullptr, nullptr, nm_hints)) return r;
     int cur = 0;
     st.idx_next = w.idx[cur]; st.count_next = cnt + cur;
     HIP_TRY(misti::launch_nm_begin(st, w.llk0, sm));
@@ -889,7 +896,7 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
             // of the NEXT iteration and drops the count of live starts into the host's pinned word (nm_spec_step_kernel: the live
             // starts of a speculative iteration fit one workgroup); only the first speculative iteration launches a points kernel
             if (!spec_primed) { HIP_TRY(misti::launch_nm_spec_points(st, bound, sm)); spec_primed = true; }
-            if (int r = run_dev(c, bound * K, st.ps_split, st.ps, nullptr, 1, w.d_row, w.llk_spec, nullptr, nullptr, nullptr, nullptr)) return r;
+            if (int r = run_dev(c, bound * K, st.ps_split, st.ps, nullptr, 1, w.d_row, w.llk_spec, nullptr, nullptr, nullptr, nullptr, nm_hints)) return r;
             // (no memsets here: the points step zeroes the next slot counter, and the reflection-split array is only read by the
             //  three-batch path, which a search never returns to - the number of live starts only falls)
             misti::NmState nx = st;
@@ -897,11 +904,11 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
             HIP_TRY(misti::launch_nm_spec_step(st, nx, bound, w.llk_spec, (int32_t*)&live_host[slot], sm));
             ++spec_iters;
         } else {
-            if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, w.d_row, w.llk1, nullptr, nullptr, nullptr, nullptr)) return r;
+            if (int r = run_dev(c, bound, st.split1, st.p1, nullptr, 1, w.d_row, w.llk1, nullptr, nullptr, nullptr, nullptr, nm_hints)) return r;
             HIP_TRY(misti::launch_nm_reflect(st, bound, w.llk1, sm));
-            if (int r = run_dev(c, bound, st.split2, st.p2, nullptr, 1, w.d_row, w.llk2, nullptr, nullptr, nullptr, nullptr)) return r;
+            if (int r = run_dev(c, bound, st.split2, st.p2, nullptr, 1, w.d_row, w.llk2, nullptr, nullptr, nullptr, nullptr, nm_hints)) return r;
             HIP_TRY(misti::launch_nm_accept(st, bound, w.llk2, sm));
-            if (int r = run_dev(c, bound * N, st.split3, st.p3, nullptr, 1, w.d_row, w.llk3, nullptr, nullptr, nullptr, nullptr)) return r;
+            if (int r = run_dev(c, bound * N, st.split3, st.p3, nullptr, 1, w.d_row, w.llk3, nullptr, nullptr, nullptr, nullptr, nm_hints)) return r;
             HIP_TRY(hipMemsetAsync(cnt + (cur ^ 1), 0, sizeof(int32_t), sm));
             HIP_TRY(hipMemsetAsync(st.split1, 0xBF, (size_t)bound * sizeof(double), sm));
             HIP_TRY(misti::launch_nm_finish(st, bound, w.llk3, sm));

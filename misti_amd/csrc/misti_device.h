@@ -201,7 +201,7 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
                           int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, const Tuning& tn, hipStream_t stream);
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, const Tuning& tn, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream);

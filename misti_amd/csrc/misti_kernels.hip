@@ -2912,11 +2912,13 @@ int64_t trunk_capacity(int64_t n_cand, const Tuning& tn) {
 // trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, const Tuning& tn, hipStream_t stream) {
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, const Tuning& tn,
+                           hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     const int cpw = correct_cands_per_wave(n_cand, tn);          // tails: one item per candidate
-    MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream)
+    // skip_post: the caller knows there is nothing for the post launch to do (no trunk left for it and no fractional split: run_dev)
+    if (!skip_post) { MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream) }
     if (!cp) {
         const int64_t threads = n_cand * (int64_t)(m.numT + 1);
         hipLaunchKernelGGL(postsplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, m, n_cand, split, params, cb);
