@@ -251,7 +251,8 @@ int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
 // hints (what an internal caller knows about its own batch; 0 from the ABI's entry points, whose split times live on the device):
 //   RUN_INTEGER_SPLITS  no split time has a fractional part (or is negative: an empty slot) - no tail for the post launch
 //   RUN_UNSHARED        every candidate has its own parameter vector: no trunk for a batch too large for one chain per wave
-enum : unsigned { RUN_INTEGER_SPLITS = 1u, RUN_UNSHARED = 2u };
+//   RUN_ONE_LENGTH      every chain has the same number of intervals: the chains need no sorting by length
+enum : unsigned { RUN_INTEGER_SPLITS = 1u, RUN_UNSHARED = 2u, RUN_ONE_LENGTH = 4u };
 int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
             double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, unsigned hints = 0) {
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
@@ -344,6 +345,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // this batch's own count - bounded, a few microseconds after the launch.
     c->batch_seq += 1;
     cb.seq = c->batch_seq;
+    cb.unsorted = (hints & RUN_ONE_LENGTH) ? 1 : 0;
     int64_t est_chains = -1;
     const volatile int32_t* hint = c->hint_host;
     if (hint && hint[1] == (int32_t)n_cand && hint[0] > 0 && hint[0] <= n_cand) est_chains = hint[0];
@@ -856,7 +858,8 @@ int nm_run(misti_ctx* c, NmWork& w, double split_time, double xatol, double fato
     st.maxiter = maxiter; st.maxfun = maxfun; st.xatol = xatol; st.fatol = fatol; st.split = split_time;
     hipStream_t sm = c->stream;
     // what the search knows about its own batches: one split time for every point (empty slots carry -1), distinct points
-    const unsigned nm_hints = (split_time == std::floor(split_time) ? RUN_INTEGER_SPLITS : 0u) | RUN_UNSHARED;
+    static const int hint_mask = [] { const char* e = getenv("MISTI_NM_HINTS"); return e ? atoi(e) : 7; }();       // diagnostic: which hints the search passes on
+    const unsigned nm_hints = ((split_time == std::floor(split_time) ? RUN_INTEGER_SPLITS : 0u) | RUN_UNSHARED | RUN_ONE_LENGTH) & (unsigned)hint_mask;
     int32_t* cnt = w.cnt;
     HIP_TRY(hipMemsetAsync(cnt, 0, 4 * sizeof(int32_t), sm));
     HIP_TRY(hipMemsetAsync(st.split1, 0xBF, S * sizeof(double), sm));          // all-0xBF bytes: a negative double = "no point in this slot"

@@ -2604,6 +2604,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
     }
     __shared__ int hist[MISTI_MAX_NUMT + 4];
     if ((int)blockIdx.x == cand_blocks) {
+        if (cb.unsorted) return;          // one split for all (the caller says): candidates are dispatched in their own order (below)
         const int nb = numT + 3;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
         __syncthreads();
@@ -2635,6 +2636,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
         if (i == 0) { cb.z_n_chains[0] = 0; cb.z_n_chains[1] = 0; cb.z_n_chains[2] = 0; cb.z_n_chains[3] = 0; }
     }
     if (i < n) {
+        if (cb.unsorted) order[i] = (int32_t)i;
         // the key: the parameter bits and, with per-candidate band bounds, the (start, end) pairs as given (end == -1
         // stays symbolic: members of a chain may differ in their split, never in where a band starts or ends)
         uint64_t h = 0x243f6a8885a308d3ull;
@@ -2642,6 +2644,12 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
         const int32_t* ab = cb.bounds ? cb.bounds + i * NB2 : nullptr;
         for (int k = 0; k < P; ++k) h = mix64(h ^ (uint64_t)__double_as_longlong(a[k]));
         if (ab) for (int k = 0; k < NB2; ++k) h = mix64(h ^ (uint64_t)(uint32_t)ab[k]);
+        const double st = split_time[i];
+        // a candidate without a valid split time (an EMPTY SLOT of a batched search: negative) starts probing at a slot of its own:
+        // thousands of them carry one and the same parameter vector, and their inserts would queue on one table entry (measured:
+        // the 32 768 empty slots of a Nelder-Mead shrink batch made this kernel 0.72 ms).  Where they end up sharing a chain it is
+        // a chain of no intervals.
+        if (!(st >= 0)) h = mix64(h ^ (uint64_t)i);
         uint32_t sl = (uint32_t)(h >> 20) & cb.tmask;
         for (;;) {
             const int prev = atomicCAS(&cb.table[sl], 0, (int)i + 1);
@@ -2650,6 +2658,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
                 cb.chain_slot[ch] = (int32_t)sl;
                 cb.rep[ch] = (int32_t)i;
                 cb.slot_chain[sl] = ch;
+                if (cb.unsorted) cb.chain_order[ch] = ch;
                 break;
             }
             const double* b = params + (int64_t)(prev - 1) * P;
@@ -2660,7 +2669,6 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
             sl = (sl + 1) & cb.tmask;
         }
         cb.slot_of[i] = (int32_t)sl;
-        const double st = split_time[i];
         int need = 0;
         if (st >= 0 && st <= (double)numT) { need = (int)st; if (need > numT - 1) need = numT - 1; }   // full intervals before the (fractional) split
         atomicMax(&cb.slot_len[sl], need);
@@ -2686,6 +2694,10 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
     if (!is_last) return;
     __threadfence();
     const int nch = __hip_atomic_load(cb.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cb.unsorted) {                                   // one length for all chains (the caller says): the order of arrival will do
+        if (cb.hint && threadIdx.x == 0) { cb.hint[0] = nch; cb.hint[1] = (int32_t)n; __threadfence_system(); cb.hint[2] = cb.seq; }
+        return;
+    }
     auto len_of = [&](int ch) {
         const int sl = __hip_atomic_load(&cb.chain_slot[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int L = __hip_atomic_load(&cb.slot_len[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
