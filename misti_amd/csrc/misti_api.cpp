@@ -345,7 +345,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // this batch's own count - bounded, a few microseconds after the launch.
     c->batch_seq += 1;
     cb.seq = c->batch_seq;
-    cb.unsorted = (hints & RUN_ONE_LENGTH) ? 1 : 0;
+    cb.unsorted = (hints & RUN_ONE_LENGTH) ? 3 : 0;          // bit 0: candidates in their own order, bit 1: chains in order of arrival
     int64_t est_chains = -1;
     const volatile int32_t* hint = c->hint_host;
     if (hint && hint[1] == (int32_t)n_cand && hint[0] > 0 && hint[0] <= n_cand) est_chains = hint[0];

@@ -80,7 +80,8 @@ struct ChainBufs {
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
     int32_t* hint;          // host-pinned [3] or NULL: {chains, candidates, batch tag}, written by the last block of discover_kernel
     int32_t seq;            // this batch's tag
-    int32_t unsorted;       // 1: the caller knows its chains are all of one length - setup_kernel leaves them in order of arrival (no sort)
+    int32_t unsorted;       // the caller knows its batch has one split time: bit 0 - candidates are dispatched in their own order, bit 1 - chains in
+                            // order of arrival (setup_kernel sorts neither)
     const int32_t* bounds;  // [n][n_band][2] per-candidate (start, end) of every band, or NULL: the model's
     double* post_lam;       // [n][numT+1] default fit: rates after the split (postsplit_kernel -> spectrum kernel)
     int32_t* post_word;     // [n][numT+1] their solver words, or NULL (trace off)

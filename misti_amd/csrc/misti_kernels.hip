@@ -2602,30 +2602,50 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
         if (r < n_rep) consts[r] = llh_const_of(jsfs + r * 8, unfolded);
         return;
     }
-    __shared__ int hist[MISTI_MAX_NUMT + 4];
+    constexpr int SORT_SUB = 32;       // copies of every bin of the candidate sort (lane mod 32 picks one: fewer conflicts, and - measured - a dispatch order within a split that kernel 2 likes better: 0.39 -> 0.36 ms on config2x16)
+    __shared__ int hist[(MISTI_MAX_NUMT + 4) * SORT_SUB];
     if ((int)blockIdx.x == cand_blocks) {
-        if (cb.unsorted) return;          // one split for all (the caller says): candidates are dispatched in their own order (below)
+        if (cb.unsorted & 1) return;          // one split for all (the caller says): candidates are dispatched in their own order (below)
         const int nb = numT + 3;
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+        for (int i = threadIdx.x; i < nb * SORT_SUB; i += blockDim.x) hist[i] = 0;
         __syncthreads();
-        auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return numT + 1 - k; };
-        // one block for the whole batch: four candidates per thread and trip (a trip is a global load and a shared-memory atomic
-        // one after the other; at 65 536 candidates the plain loop was 0.12 ms of a 2.3 ms batch)
-        const int64_t step = 4 * (int64_t)blockDim.x;
+        const int sub = threadIdx.x & (SORT_SUB - 1);
+        auto key = [&](double st) { int k = (st >= 0 && st < (double)(numT + 1)) ? (int)st : 0; return (numT + 1 - k) * SORT_SUB + sub; };
+        // One block for the whole batch (a counting sort by descending split index).  Two things bound it, both measured on 65 536
+        // candidates (0.095 ms of this kernel's 0.12): the latency of the global load of a trip - hence SORT_ILP loads in flight per
+        // thread - and the shared-memory atomics: a sweep is ordered split-major, so the 64 lanes of a wave hit ONE bin, a 64-way
+        // conflict per instruction - hence SORT_SUB copies of every bin (a 2-way conflict), summed in the prefix step.
+        constexpr int SORT_ILP = 8;
+        const int64_t step = SORT_ILP * (int64_t)blockDim.x;
         for (int64_t i0 = threadIdx.x; i0 < n; i0 += step) {
-            double st[4];
-            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
-            for (int u = 0; u < 4; ++u) if (i0 + u * (int64_t)blockDim.x < n) atomicAdd(&hist[key(st[u])], 1);
+            double st[SORT_ILP];
+#pragma unroll
+            for (int u = 0; u < SORT_ILP; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < SORT_ILP; ++u) if (i0 + u * (int64_t)blockDim.x < n) atomicAdd(&hist[key(st[u])], 1);
         }
         __syncthreads();
-        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { int c = hist[b]; hist[b] = acc; acc += c; } }
+        // exclusive prefix over (bin, copy): within a bin by its thread, over the bins by thread 0
+        __shared__ int bin_base[MISTI_MAX_NUMT + 4];
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+            int acc = 0;
+            for (int c = 0; c < SORT_SUB; ++c) { const int v = hist[b * SORT_SUB + c]; hist[b * SORT_SUB + c] = acc; acc += v; }
+            bin_base[b] = acc;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < nb; ++b) { const int c = bin_base[b]; bin_base[b] = acc; acc += c; } }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) for (int c = 0; c < SORT_SUB; ++c) hist[b * SORT_SUB + c] += bin_base[b];
         __syncthreads();
         for (int64_t i0 = threadIdx.x; i0 < n; i0 += step) {
-            double st[4];
-            int pos[4];
-            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
-            for (int u = 0; u < 4; ++u) pos[u] = i0 + u * (int64_t)blockDim.x < n ? atomicAdd(&hist[key(st[u])], 1) : 0;
-            for (int u = 0; u < 4; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; if (i < n) order[pos[u]] = (int32_t)i; }
+            double st[SORT_ILP];
+            int pos[SORT_ILP];
+#pragma unroll
+            for (int u = 0; u < SORT_ILP; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; st[u] = i < n ? split_time[i] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < SORT_ILP; ++u) pos[u] = i0 + u * (int64_t)blockDim.x < n ? atomicAdd(&hist[key(st[u])], 1) : 0;
+#pragma unroll
+            for (int u = 0; u < SORT_ILP; ++u) { const int64_t i = i0 + u * (int64_t)blockDim.x; if (i < n) order[pos[u]] = (int32_t)i; }
         }
         return;
     }
@@ -2636,7 +2656,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
         if (i == 0) { cb.z_n_chains[0] = 0; cb.z_n_chains[1] = 0; cb.z_n_chains[2] = 0; cb.z_n_chains[3] = 0; }
     }
     if (i < n) {
-        if (cb.unsorted) order[i] = (int32_t)i;
+        if (cb.unsorted & 1) order[i] = (int32_t)i;
         // the key: the parameter bits and, with per-candidate band bounds, the (start, end) pairs as given (end == -1
         // stays symbolic: members of a chain may differ in their split, never in where a band starts or ends)
         uint64_t h = 0x243f6a8885a308d3ull;
@@ -2658,7 +2678,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
                 cb.chain_slot[ch] = (int32_t)sl;
                 cb.rep[ch] = (int32_t)i;
                 cb.slot_chain[sl] = ch;
-                if (cb.unsorted) cb.chain_order[ch] = ch;
+                if (cb.unsorted & 2) cb.chain_order[ch] = ch;
                 break;
             }
             const double* b = params + (int64_t)(prev - 1) * P;
@@ -2694,7 +2714,7 @@ void setup_kernel(DevModel m, int64_t n, const double* __restrict__ params, cons
     if (!is_last) return;
     __threadfence();
     const int nch = __hip_atomic_load(cb.n_chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cb.unsorted) {                                   // one length for all chains (the caller says): the order of arrival will do
+    if (cb.unsorted & 2) {                                   // one length for all chains (the caller says): the order of arrival will do
         if (cb.hint && threadIdx.x == 0) { cb.hint[0] = nch; cb.hint[1] = (int32_t)n; __threadfence_system(); cb.hint[2] = cb.seq; }
         return;
     }
