@@ -396,13 +396,20 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         if (yield_nfev > 0 && busy_from > 0 && busy() >= busy_from) yield_nfev = 0;
     }
     HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, yield_nfev, c->stream), a, b);
+    // Kernel 2 in single-wave workgroups (they slip into any free wave slot while other batches' chain kernels are resident: +21 % on
+    // the headline grid with 20 batches in flight) - except behind a chip-filling one-chain-per-wave launch of this context's own:
+    // there the next such launch was measured 18 % slower after single-wave workgroups (1.66 -> 1.96 ms on 1 024 chains; the placement
+    // of its chain and trunk waves on the SIMDs follows where the previous kernel's workgroups ended), and such a batch runs alone -
+    // with other contexts busy it would have taken the packed shape.
+    const bool single_waves = c->tune.k2_single_waves >= 0 ? c->tune.k2_single_waves != 0 : !(follow && est_chains > 256);
     if (int r = record_end(c, 0, a, b)) return r;
     if (c->timing) c->launches[0] += 1;
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
     if (int r = record_begin(c, 1, &a, &b)) return r;
     HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                      n_rep, d_jsfs, d_consts, d_llk, follow, (hints & RUN_INTEGER_SPLITS) && (follow || ntr == 0), c->tune, c->stream), a, b);
+                                      n_rep, d_jsfs, d_consts, d_llk, follow, (hints & RUN_INTEGER_SPLITS) && (follow || ntr == 0), single_waves,
+                                      c->tune, c->stream), a, b);
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {

@@ -178,7 +178,7 @@ hipError_t launch_bh_result(const BhState& bh, double* x, double* llh, hipStream
 constexpr int LLK_INLINE_MAX = 8;
 
 hipError_t upload_tables(const DevTables& t);
-size_t spectrum_lds_bytes(int numT);
+size_t spectrum_lds_bytes(int numT, int wpb);
 // Diagnostic overrides of the launch shape, read from the environment ONCE per context (misti_create) - never on the batch path.
 struct Tuning {
     int chains_per_wave = 0;   // MISTI_CHAINS_PER_WAVE: 1 | 2 | 4 | 8 | 10 forces the packing of the chain launch
@@ -189,6 +189,7 @@ struct Tuning {
     int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
     int yield_nfev = -1;       // MISTI_YIELD_NFEV: evaluations after which a solve of a PACKED launch yields its chain to correct_resume_kernel
                                // (-1: YIELD_NFEV; 0: never)
+    int k2_single_waves = -1;  // MISTI_K2_SINGLE_WAVES: 1 / 0 forces kernel 2's workgroups to one / four waves (-1: chosen per batch, run_dev)
     int busy_contexts = -1;    // MISTI_FOLLOW_BUSY_CONTEXTS: other contexts with a batch in flight from which on a batch of more than
                                // FOLLOW_BUSY_CHAINS chains is packed (-1: FOLLOW_BUSY_CONTEXTS; 0: never look, always the latency shape)
 };
@@ -203,7 +204,7 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
                           int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, const Tuning& tn, hipStream_t stream);
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, bool single_waves, const Tuning& tn, hipStream_t stream);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream);

@@ -2265,8 +2265,12 @@ void postsplit_kernel(DevModel m, int64_t n_cand, const double* __restrict__ spl
 // (JAFSpectrum, :467-540).  One wavefront per candidate; lane = interval in the prologue,
 // lane = state of the 44-state chain afterwards.
 // LDS per wave (doubles): xbuf[128] (re | im) | lc[2*(numT0+1)]
-template <bool CPFIT>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64, 4)      // 4 waves per SIMD: a 4 096-candidate batch is resident in one round
+// WPB: candidates (waves) per workgroup - 4, or 1 (launch_spectrum: `single_waves`).  A four-wave workgroup needs four free wave slots
+// on one compute unit at the same moment; with other contexts' chain kernels resident everywhere those seldom come free together, and
+// single-wave workgroups slip into every slot as it opens: measured with 20 batches in flight, the headline grid 2.96 -> 3.59e7 evals/s,
+// config2x16 8.2 -> 9.1e7.  Alone on the device the kernel itself runs the same either way.
+template <bool CPFIT, int WPB = WAVES_PER_BLOCK>
+__global__ __launch_bounds__(WPB * 64, 4)      // 4 waves per SIMD: a 4 096-candidate batch is resident in one round
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
                      double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out,
@@ -2275,7 +2279,7 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     const int lane = lane_id();
     // everything per candidate is wave-uniform: keep it in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t slot = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int64_t slot = (int64_t)blockIdx.x * WPB + wave;
     if (slot >= n_cand) return;
 #ifdef MISTI_STAMP2
     long long s_[8];
@@ -2831,7 +2835,7 @@ hipError_t upload_tables(const DevTables& t) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(DevTables));
 }
 
-size_t spectrum_lds_bytes(int numT) { return (size_t)WAVES_PER_BLOCK * (128 + 2 * (numT + 1)) * sizeof(double); }
+size_t spectrum_lds_bytes(int numT, int wpb) { return (size_t)wpb * (128 + 2 * (numT + 1)) * sizeof(double); }
 
 // Work items per wavefront.  Kernel 1 holds two wavefronts per SIMD (208 VGPRs), 2 048 on the chip: as few
 // items per wave as keep the launch within one resident round - 1, 2, 4 - and beyond that ten (six lanes per
@@ -2859,6 +2863,7 @@ Tuning read_tuning() {
     t.min_blocks = num("MISTI_FOLLOW_MIN_BLOCKS");
     t.busy_contexts = getenv("MISTI_FOLLOW_BUSY_CONTEXTS") ? num("MISTI_FOLLOW_BUSY_CONTEXTS") : -1;
     t.yield_nfev = getenv("MISTI_YIELD_NFEV") ? num("MISTI_YIELD_NFEV") : -1;
+    t.k2_single_waves = getenv("MISTI_K2_SINGLE_WAVES") ? num("MISTI_K2_SINGLE_WAVES") : -1;
     return t;
 }
 
@@ -2944,8 +2949,8 @@ int64_t trunk_capacity(int64_t n_cand, const Tuning& tn) {
 // trunks + tails in one launch, then the candidates (with the replicate epilogue when n_rep is small)
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, const Tuning& tn,
-                           hipStream_t stream) {
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, bool single_waves,
+                           const Tuning& tn, hipStream_t stream) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     const int cpw = correct_cands_per_wave(n_cand, tn);          // tails: one item per candidate
@@ -2956,13 +2961,14 @@ hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* ord
         hipLaunchKernelGGL(postsplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, m, n_cand, split, params, cb);
     }
     const int n_inline = (n_rep > 0 && n_rep <= LLK_INLINE_MAX) ? (int)n_rep : 0;
-    dim3 grid((unsigned)((n_cand + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK));
-    if (cp)
-        hipLaunchKernelGGL(spectrum_kernel<true>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk);
-    else
-        hipLaunchKernelGGL(spectrum_kernel<false>, grid, dim3(WAVES_PER_BLOCK * 64), spectrum_lds_bytes(m.numT), stream,
-                           m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk);
+    const int wpb = single_waves ? 1 : WAVES_PER_BLOCK;
+    dim3 grid((unsigned)((n_cand + wpb - 1) / wpb));
+#define MISTI_SPECTRUM_LAUNCH(CP, W)                                                                                                   \
+    hipLaunchKernelGGL((spectrum_kernel<CP, W>), grid, dim3(W * 64), spectrum_lds_bytes(m.numT, W), stream,                            \
+                       m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk)
+    if (cp) { if (single_waves) MISTI_SPECTRUM_LAUNCH(true, 1); else MISTI_SPECTRUM_LAUNCH(true, WAVES_PER_BLOCK); }
+    else { if (single_waves) MISTI_SPECTRUM_LAUNCH(false, 1); else MISTI_SPECTRUM_LAUNCH(false, WAVES_PER_BLOCK); }
+#undef MISTI_SPECTRUM_LAUNCH
     return hipGetLastError();
 }
 
