@@ -110,12 +110,14 @@ def main():
                 "SQ_ACTIVE_INST_* count quad-cycles, SQ_INSTS_* instructions per wave." % wl)
         json.dump({"note": note, "workload": wl, "counters": counters}, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
         entry = {"source": "profiles/%s_pmc_%s.json" % (tag, wl)}
-        for key, pats in (("correct", KERNEL1[wl]), ("post", ("misti::post_kernel",)), ("spectrum", ("misti::spectrum_kernel<true>",))):
+        for key, pats in (("correct", KERNEL1[wl]), ("post", ("misti::post_kernel",)), ("spectrum", ("misti::spectrum_kernel<true",))):
             hbm, v, names = 0.0, {}, []
             for pat in pats:
-                for k, d in counters.items():
-                    if not k.startswith(pat):
-                        continue
+                hits = [k for k in counters if k.startswith(pat)]
+                if key == "spectrum" and len(hits) > 1:      # two instantiations (one / four waves per workgroup): the one the timed batches ran
+                    hits = [max(hits, key=lambda k: counters[k].get("SQ_INSTS_VALU", 0.0))]
+                for k in hits:
+                    d = counters[k]
                     names.append(k)
                     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
                         hbm += (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
