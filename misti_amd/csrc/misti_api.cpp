@@ -126,6 +126,19 @@ namespace {
 // launch shape of mid-sized batches depends on it: latency when alone, throughput when not - misti_consts.h FOLLOW_BUSY_*).
 std::mutex g_ctx_mu;
 std::vector<misti_ctx*> g_ctxs;
+// the device-wide table of chain waves per (compute unit, SIMD) (correct_follow_kernel's role choice): one per device, zeroed once
+int32_t* g_pair_table[16] = {};
+int32_t* pair_table(int device) {
+    if (device < 0 || device >= 16) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (!g_pair_table[device]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, misti::PAIR_TABLE * sizeof(int32_t)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, misti::PAIR_TABLE * sizeof(int32_t)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_pair_table[device] = (int32_t*)p;
+    }
+    return g_pair_table[device];
+}
 
 int other_contexts_busy(const misti_ctx* self) {
     int busy = 0;
@@ -308,6 +321,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.trunk = ntr ? c->ws_trunk.as<double>() : nullptr;
         cb.trunk_cap = (int64_t)ntr;
         cb.hint = c->hint_dev;
+        cb.simd_load = c->tune.pairing ? pair_table(c->device) : nullptr;
         cb.bounds = c->dm.n_band > 0 ? d_bounds : nullptr;
         cb.post_lam = nullptr;
         cb.post_word = nullptr;

@@ -26,6 +26,7 @@ constexpr int FOLLOW_BUSY_CHAINS = 128; // ... but only up to this many while th
                                         // 256 chains 3.7e7 one per wave, 4.7e7 packed; 512: 4.0e7 / 6.3e7; 1 024 (config2x16): 4.2e7 / 7.7e7
 constexpr int FOLLOW_BUSY_CONTEXTS = 3;
 constexpr int YIELD_NFEV = 8;           // packed launches: a solve still running after this many evaluations hands its chain to the resume launch
+constexpr int PAIR_TABLE = 8 * 8 * 2 * 16 * 4;   // XCC x SE x SH x CU x SIMD counters of the placement-aware role choice (correct_follow_kernel)
 constexpr int FOLLOW_MIN_BLOCKS = 256;   // workgroups of the one-chain-per-wave launch whatever the (possibly stale) chain-count hint says
 constexpr int SMOOTH_REPS = 4;        // numT <= 64 * SMOOTH_REPS (smoothing pass keeps runs in registers)
 }  // namespace misti

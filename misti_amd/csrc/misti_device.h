@@ -78,6 +78,7 @@ struct ChainBufs {
     double* trunk;          // [trunk_cap][numT][TRUNK_REC] per chain: 44-state vector + occupation integrals before interval t
     int32_t* trunk_ok;      // [trunk_cap] per chain: last valid record
     int64_t trunk_cap;      // chains the trunk buffer holds (0: no trunk)
+    int32_t* simd_load;     // [PAIR_TABLE] chain waves resident per (compute unit, SIMD) - all contexts of the device share it - or NULL (correct_follow_kernel)
     int32_t* hint;          // host-pinned [3] or NULL: {chains, candidates, batch tag}, written by the last block of discover_kernel
     int32_t seq;            // this batch's tag
     int32_t unsorted;       // the caller knows its batch has one split time: bit 0 - candidates are dispatched in their own order, bit 1 - chains in
@@ -189,6 +190,7 @@ struct Tuning {
     int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
     int yield_nfev = -1;       // MISTI_YIELD_NFEV: evaluations after which a solve of a PACKED launch yields its chain to correct_resume_kernel
                                // (-1: YIELD_NFEV; 0: never)
+    bool pairing = true;       // MISTI_FOLLOW_PAIRING=0: the chain always on the first wave of its workgroup (default: placement-aware, correct_follow_kernel)
     int k2_single_waves = -1;  // MISTI_K2_SINGLE_WAVES: 1 / 0 forces kernel 2's workgroups to one / four waves (-1: chosen per batch, run_dev)
     int busy_contexts = -1;    // MISTI_FOLLOW_BUSY_CONTEXTS: other contexts with a batch in flight from which on a batch of more than
                                // FOLLOW_BUSY_CHAINS chains is packed (-1: FOLLOW_BUSY_CONTEXTS; 0: never look, always the latency shape)

@@ -2185,7 +2185,7 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     double* tk = lds + 3 * (size_t)m.numT;
     double* lc_sh = tk + 128 + 2 * (size_t)(m.numT + 1);
     volatile int* flags = (volatile int*)(lc_sh + 2 * (size_t)m.numT);          // count, done | queue position of the chain in progress
-    double* pre = lc_sh + 2 * (size_t)m.numT + 2;                              // per-interval constants of the chain in progress
+    double* pre = lc_sh + 2 * (size_t)m.numT + 4;                              // per-interval constants of the chain in progress (after 8 ints: flags, queue position, role exchange)
     // candidate -> chain (see correct_kernel)
     for (int64_t i = (int64_t)blockIdx.x * 128 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 128) cb.of[i] = cb.slot_chain[cb.slot_of[i]];
     // Workgroups PULL chains from a queue, the longest first (cb.chain_order, sorted by setup_kernel; head = n_chains[2]): any
@@ -2194,13 +2194,41 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     const int64_t n_live = cb.n_chains[0];
     if ((int64_t)blockIdx.x >= n_live) return;                                // more workgroups than chains (a generous grid): leave at once
     int* next = (int*)(flags + 2);
+    // Which of the two waves runs the chain: the one on the SIMD that hosts fewer chain waves right now (of any context: a device-wide
+    // table of counters per compute unit and SIMD).  A chain wave beside a trunk wave runs at full speed, beside another chain
+    // wave it does not (1.66 against 1.96 ms on 1 024 chains), and which SIMDs a workgroup's waves land on is the dispatcher's choice.
+    // Measured with 20 batches in flight on the headline grid: 3.60 -> 3.76e7 evals/s; alone nothing changes (the dispatcher's own
+    // placement on an idle chip is already the good one).  The counters only steer - a stale or shared one costs speed, never a result.
+    bool chain_role = threadIdx.x < 64;
+    int32_t* my_load = nullptr;
+    if (cb.simd_load) {
+        int* ex = next + 1;                              // [4]: SIMD of wave 0, of wave 1, table index of the compute unit, role swap
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID: wave [3:0] simd [5:4] cu [11:8] sh [12] se [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);         // HW_REG_XCC_ID [3:0]
+        const int simd = (hw >> 4) & 3;
+        if ((threadIdx.x & 63) == 0) ex[threadIdx.x >> 6] = simd;
+        if (threadIdx.x == 0) ex[2] = (int)((((xcc & 7) * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 15)) * 4;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t* t = cb.simd_load + ex[2];
+            const int c0 = __hip_atomic_load(&t[ex[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int c1 = __hip_atomic_load(&t[ex[1]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int sw = c1 < c0 ? 1 : 0;              // wave 1 takes the chain
+            ex[3] = sw;
+            atomicAdd(&t[ex[sw]], 1);
+        }
+        __syncthreads();
+        chain_role = ((int)(threadIdx.x >> 6) ^ ex[3]) == 0;
+        my_load = cb.simd_load + ex[2] + ex[ex[3]];
+        __syncthreads();
+    }
     for (;;) {
         if (threadIdx.x == 0) { lds_put(flags, 0); lds_put(flags + 1, 0); *next = atomicAdd(&cb.n_chains[2], 1); }
         __syncthreads();
         const int64_t pos = *next;
         if (pos >= n_live) break;
         const int64_t ch = cb.chain_order[pos];
-        if (threadIdx.x < 64) {
+        if (chain_role) {
             // a launch that fills the chip: the longest chains - the ones the launch waits for - get the issue priority on the SIMD
             // they share with another wave (s_setprio; measured on 1 024 chains: 2.04 -> 1.92 ms per call; on the headline grid's 64
             // chains it changes nothing alone and costs 1 % with 20 batches in flight, so not there)
@@ -2211,12 +2239,13 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
             }
             correct_body<CPFIT, 64, false, true>(m, n_items, cb, split_time, params, ch, lds, lc_sh, flags, pre);
             lds_order();
-            if (threadIdx.x == 0) lds_put(flags + 1, 1);                     // whatever way the chain ended
+            if (lane_id() == 0) lds_put(flags + 1, 1);                       // whatever way the chain ended
         } else {
             trunk_follow(m, n_items, params, cb, ch, tk, lc_sh, flags);
         }
         __syncthreads();                                                     // both waves are done with the hand-over area
     }
+    if (my_load && threadIdx.x == 0) atomicSub(my_load, 1);
 }
 
 // Everything that waits for the chains and that the candidate kernel waits for, in ONE launch: the
@@ -2872,6 +2901,7 @@ Tuning read_tuning() {
     t.busy_contexts = getenv("MISTI_FOLLOW_BUSY_CONTEXTS") ? num("MISTI_FOLLOW_BUSY_CONTEXTS") : -1;
     t.yield_nfev = getenv("MISTI_YIELD_NFEV") ? num("MISTI_YIELD_NFEV") : -1;
     t.k2_single_waves = getenv("MISTI_K2_SINGLE_WAVES") ? num("MISTI_K2_SINGLE_WAVES") : -1;
+    t.pairing = !(getenv("MISTI_FOLLOW_PAIRING") && getenv("MISTI_FOLLOW_PAIRING")[0] == '0');
     return t;
 }
 
@@ -2927,7 +2957,7 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     if (follow) {
-        const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT + 2 + 6 * (size_t)m.numT) * sizeof(double);
+        const size_t lds = (3 * (size_t)m.numT + 128 + 2 * (size_t)(m.numT + 1) + 2 * (size_t)m.numT + 4 + 6 * (size_t)m.numT) * sizeof(double);
         // one workgroup per chain expected, at most the resident 1 024 (two waves per SIMD; 512 for the default fit at one): the
         // workgroups pull chains from a queue, so any grid is correct and a stale hint costs at most idle or missing workgroups
         int64_t blocks = (est_chains > 0 && est_chains < n_cand) ? est_chains : n_cand;

@@ -229,3 +229,35 @@ def test_default_fit_yield_is_off_by_default_and_bit_identical_when_forced():
         for name in ("llk", "jafs", "lc"):
             assert np.array_equal(getattr(out[a], name), getattr(out[b], name), equal_nan=True), (a, name)
         assert np.array_equal(out[a].pr[:, :-1, :], out[b].pr[:, :-1, :], equal_nan=True), a
+
+
+def test_placement_aware_roles_do_not_change_results():
+    """correct_follow_kernel gives the chain to the wave on the SIMD with fewer chain waves (a device-wide table of counters) and the
+    trunk to the other; MISTI_FOLLOW_PAIRING=0 keeps the chain on the first wave.  Which wave runs what changes no bit - the headline
+    grid both ways, and again while a second context keeps chain waves resident (the counters then actually differ)."""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a))
+    out = {}
+    for name, env in (("paired", {}), ("fixed", {"MISTI_FOLLOW_PAIRING": "0"})):
+        os.environ.update(env)
+        try:
+            with Engine(w.times, w.lh, **w.engine_kwargs()) as e, Engine(w.times, w.lh, **w.engine_kwargs()) as other:
+                e.evaluate(w.split_time, w.params, w.jsfs)
+                import torch
+                dev = torch.device("cuda", 0)
+                d_split = torch.as_tensor(w.split_time, device=dev)
+                d_par = torch.as_tensor(w.params, device=dev).contiguous()
+                d_j = torch.as_tensor(w.jsfs, device=dev).contiguous()
+                llk = torch.empty((w.n_cand, 1), dtype=torch.float64, device=dev)
+                for _ in range(4):                                   # the other context's batches in flight on its own stream
+                    other.evaluate_dev(w.n_cand, d_split.data_ptr(), d_par.data_ptr(), 1, d_j.data_ptr(), llk.data_ptr())
+                out[name] = e.evaluate(w.split_time, w.params, w.jsfs, want_lc=True, want_pr=True)
+                other.sync()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    a, b = out["paired"], out["fixed"]
+    assert np.array_equal(a.status, b.status)
+    for name in ("llk", "jafs", "lc", "pr"):
+        assert np.array_equal(getattr(a, name), getattr(b, name), equal_nan=True), name
