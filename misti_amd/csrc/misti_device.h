@@ -102,7 +102,8 @@ __device__ __forceinline__ int64_t chain_of(const ChainBufs& cb, int64_t cand) {
 __device__ __forceinline__ int chain_len(const ChainBufs& cb, int64_t ch) { return cb.slot_len[cb.chain_slot[ch]]; }
 
 // Batched Nelder-Mead (misti_nm.hip): everything a start owns, in HBM.  V = N + 1 vertices.
-enum { NM_NONE = 0, NM_REFLECT = 1, NM_EXPAND = 2, NM_CONTRACT = 3, NM_INSIDE = 4 };
+enum { NM_NONE = 0, NM_REFLECT = 1, NM_EXPAND = 2, NM_CONTRACT = 3, NM_INSIDE = 4,
+       NM_CUT = 5 };        // the evaluation budget (maxfev) ran out before the iteration's second point: SciPy abandons the iteration there
 struct NmState {
     int64_t S;              // starts
     int N;                  // parameters
@@ -119,7 +120,8 @@ struct NmState {
     int32_t* nfev;          // [S] SciPy's fcalls
     int32_t* done;          // [S] -1 while running; 0 converged, 1 evaluation budget, 2 iteration budget
     int32_t* kind;          // [S] NM_* of the iteration in progress
-    int32_t* shrunk;        // [S]
+    int32_t* shrunk;        // [S] 0: no shrink in the iteration in progress; 1 + n: a shrink of which n vertices were evaluated (n < N: the budget
+                            //     ran out inside it - vertex n + 1 is moved but keeps its old value, the rest is untouched, as in SciPy)
     // per slot of the iteration's batches (live starts compacted)
     double* p1;             // [S][N]    reflection points
     double* p2;             // [S][N]    expansion / contraction points

@@ -13,6 +13,12 @@
 // split time: it leaves the spectrum kernel at once with -inf and costs nothing.  Nothing of the search crosses PCIe
 // inside the loop except that 4-byte count.
 //
+// Evaluation budget (maxfev; basin hopping's minimisations run with SciPy's default maxiter = maxfev = 200 N): SciPy's wrapper
+// (_wrap_scalar_function_maxfun_validation) raises BEFORE the call that would exceed it, the iteration in progress is abandoned -
+// nothing accepted, `iterations` not incremented, a shrink applied up to and including the vertex whose evaluation was refused
+// (which keeps its old value) - the simplex is sorted and the loop ends with warnflag 1.  Restated here per evaluation
+// (NM_CUT, NmState::shrunk): nfev never exceeds maxfev.
+//
 // Arithmetic: SciPy evaluates  (1 + rho) * xbar - rho * worst  etc. with one rounding per operation.  The library is
 // built with -ffp-contract=fast (which ignores contraction pragmas, and HIP's __dmul_rn / __dadd_rn are plain operators
 // in a header), so every product that feeds a sum passes through rn(): an empty asm the compiler cannot see through,
@@ -128,8 +134,9 @@ void nm_begin_kernel(NmState st, const double* __restrict__ llk0) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= st.S) return;
     const int V = st.N + 1;
-    for (int i = 0; i < V; ++i) st.fsim[s * V + i] = objective(llk0[s * V + i]);
-    st.nfev[s] = V;
+    const int n0 = (int64_t)V <= st.maxfun ? V : (int)st.maxfun;             // fsim starts as +inf; evaluations beyond the budget are refused
+    for (int i = 0; i < V; ++i) st.fsim[s * V + i] = i < n0 ? objective(llk0[s * V + i]) : INFINITY;
+    st.nfev[s] = n0;
     sort_simplex(st, s);
     next_reflection(st, s);
 }
@@ -161,9 +168,11 @@ void nm_reflect_kernel(NmState st, int64_t bound, const double* __restrict__ llk
         kind = NM_INSIDE;                                   // (1 - psi) * xbar + psi * sim[-1]
         for (int k = 0; k < N; ++k) p2[k] = rn((1.0 - NM_PSI) * centroid(x, N, k)) + rn(NM_PSI * x[N * N + k]);
     }
+    if (kind != NM_REFLECT && (int64_t)st.nfev[s] >= st.maxfun) kind = NM_CUT;      // the second point's evaluation is refused
     st.kind[s] = kind;
-    if (kind == NM_REFLECT) for (int k = 0; k < N; ++k) p2[k] = 0.0;
-    st.split2[i] = kind == NM_REFLECT ? -1.0 : st.split;
+    const bool second = kind != NM_REFLECT && kind != NM_CUT;
+    if (!second) for (int k = 0; k < N; ++k) p2[k] = 0.0;
+    st.split2[i] = second ? st.split : -1.0;
 }
 
 // the second value is in: replace the worst vertex, or shrink (then the N shrunk vertices are the third batch)
@@ -184,25 +193,33 @@ void nm_accept_kernel(NmState st, int64_t bound, const double* __restrict__ llk2
     const double fxr = st.fxr[s];
     const double* take = p1;
     double ftake = fxr;
-    if (kind != NM_REFLECT) {
+    if (kind != NM_REFLECT && kind != NM_CUT) {
         const double f2 = objective(llk2[i]);
         st.nfev[s] += 1;
         if (kind == NM_EXPAND) { if (f2 < fxr) { take = p2; ftake = f2; } }
         else if (kind == NM_CONTRACT) { if (f2 <= fxr) { take = p2; ftake = f2; } else shrink = true; }
         else { if (f2 < f[N]) { take = p2; ftake = f2; } else shrink = true; }
     }
-    if (!shrink) { for (int k = 0; k < N; ++k) x[N * N + k] = take[k]; f[N] = ftake; }
-    else
-        for (int j = 1; j < V; ++j)
+    int n_eval = 0;                // shrunk vertices the budget still pays for
+    if (kind == NM_CUT) {
+        // iteration abandoned before anything was accepted
+    } else if (!shrink) { for (int k = 0; k < N; ++k) x[N * N + k] = take[k]; f[N] = ftake; }
+    else {
+        const int64_t left = st.maxfun - (int64_t)st.nfev[s];
+        n_eval = left >= N ? N : (left > 0 ? (int)left : 0);
+        const int n_move = n_eval < N ? n_eval + 1 : N;      // SciPy moves sim[j] before the call that is refused
+        for (int j = 1; j <= n_move; ++j)
             for (int k = 0; k < N; ++k) {
                 const double v = x[k] + rn(NM_SIGMA * rn(x[j * N + k] - x[k]));   // sim[0] + sigma (sim[j] - sim[0])
                 x[j * N + k] = v;
-                p3[(j - 1) * N + k] = v;
+                if (j <= n_eval) p3[(j - 1) * N + k] = v;
             }
-    st.shrunk[s] = shrink ? 1 : 0;
+    }
+    st.shrunk[s] = shrink ? 1 + n_eval : 0;
     for (int j = 0; j < N; ++j) {
-        st.split3[i * N + j] = shrink ? st.split : -1.0;
-        if (!shrink) for (int k = 0; k < N; ++k) p3[j * N + k] = 0.0;
+        const bool live = shrink && j < n_eval;
+        st.split3[i * N + j] = live ? st.split : -1.0;
+        if (!live) for (int k = 0; k < N; ++k) p3[j * N + k] = 0.0;
     }
 }
 
@@ -213,11 +230,14 @@ void nm_finish_kernel(NmState st, int64_t bound, const double* __restrict__ llk3
     if (i >= bound || i >= st.count_cur[0]) return;
     const int N = st.N, V = N + 1;
     const int64_t s = st.idx_cur[i];
+    bool cut = st.kind[s] == NM_CUT;
     if (st.shrunk[s]) {
-        for (int j = 1; j < V; ++j) st.fsim[s * V + j] = objective(llk3[i * N + (j - 1)]);
-        st.nfev[s] += N;
+        const int n_eval = st.shrunk[s] - 1;
+        for (int j = 1; j <= n_eval; ++j) st.fsim[s * V + j] = objective(llk3[i * N + (j - 1)]);
+        st.nfev[s] += n_eval;
+        cut = cut || n_eval < N;
     }
-    st.nit[s] += 1;
+    if (!cut) st.nit[s] += 1;                  // an abandoned iteration does not count (the exception skips `iterations += 1`)
     sort_simplex(st, s);
     next_reflection(st, s);
 }
@@ -263,28 +283,35 @@ __device__ __forceinline__ void spec_finish(const NmState& st, int64_t bound, co
     const double* v = llk + i * K;
     const double fxr = objective(v[0]);
     int nfev = st.nfev[s] + 1;
-    int take = 0;                 // which point replaces the worst vertex; -1: shrink
+    int take = 0;                 // which point replaces the worst vertex; -1: shrink; -2: budget ran out before the second point
     double ftake = fxr;
+    const bool broke = (int64_t)nfev >= st.maxfun;      // a second evaluation would be refused
     if (fxr < f[0]) {             // expansion
-        const double f2 = objective(v[1]); ++nfev;
-        if (f2 < fxr) { take = 1; ftake = f2; }
+        if (broke) take = -2;
+        else { const double f2 = objective(v[1]); ++nfev; if (f2 < fxr) { take = 1; ftake = f2; } }
     } else if (fxr < f[N - 1]) {
         // accepted as it is
     } else if (fxr < f[N]) {      // outside contraction
-        const double f2 = objective(v[2]); ++nfev;
-        if (f2 <= fxr) { take = 2; ftake = f2; } else take = -1;
+        if (broke) take = -2;
+        else { const double f2 = objective(v[2]); ++nfev; if (f2 <= fxr) { take = 2; ftake = f2; } else take = -1; }
     } else {                      // inside contraction
-        const double f2 = objective(v[3]); ++nfev;
-        if (f2 < f[N]) { take = 3; ftake = f2; } else take = -1;
+        if (broke) take = -2;
+        else { const double f2 = objective(v[3]); ++nfev; if (f2 < f[N]) { take = 3; ftake = f2; } else take = -1; }
     }
+    bool cut = take == -2;
+    int n_eval = 0;
     if (take >= 0) { for (int k = 0; k < N; ++k) x[N * N + k] = pt[take * N + k]; f[N] = ftake; }
-    else {
-        for (int j = 1; j < V; ++j) { for (int k = 0; k < N; ++k) x[j * N + k] = pt[(3 + j) * N + k]; f[j] = objective(v[3 + j]); }
-        nfev += N;
+    else if (take == -1) {
+        const int64_t left = st.maxfun - (int64_t)nfev;
+        n_eval = left >= N ? N : (left > 0 ? (int)left : 0);
+        const int n_move = n_eval < N ? n_eval + 1 : N;
+        for (int j = 1; j <= n_move; ++j) { for (int k = 0; k < N; ++k) x[j * N + k] = pt[(3 + j) * N + k]; if (j <= n_eval) f[j] = objective(v[3 + j]); }
+        nfev += n_eval;
+        cut = n_eval < N;
     }
     st.nfev[s] = nfev;
-    st.shrunk[s] = take < 0 ? 1 : 0;
-    st.nit[s] += 1;
+    st.shrunk[s] = take == -1 ? 1 + n_eval : 0;
+    if (!cut) st.nit[s] += 1;
     sort_simplex(st, s);
     next_reflection(st, s);
 }

@@ -67,8 +67,9 @@ def config1(spectrum_fn, n_sites=10 ** 6):
     return w
 
 
-def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0):
-    """numT = 128; grid of split index x rate of one band ``-mi 1 4 {st} {r} 1``, ``--cpfit``."""
+def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0, cpfit=True):
+    """numT = 128; grid of split index x rate of one band ``-mi 1 4 {st} {r} 1``, ``--cpfit`` (``cpfit=False``: the
+    reference's default fit, MiSTI.py:86,213)."""
     inp = synth.psmc_pair(64, 65)
     band_truth = [(0, 4, true_split, true_rate, -1)]
     mis, pus = _mis_pus(band_truth, [], true_split)
@@ -77,9 +78,9 @@ def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, t
     splits = np.arange(first_split, first_split + n_split, dtype=np.float64)
     rates = np.logspace(-3, np.log10(max_rate), n_rate)
     st, rr = np.meshgrid(splits, rates, indexing="ij")
-    w = Workload("config2: numT=128, %dx%d split x mi-rate grid, one band, --cpfit" % (n_split, n_rate),
+    w = Workload("config2: numT=128, %dx%d split x mi-rate grid, one band, %s" % (n_split, n_rate, "--cpfit" if cpfit else "default fit"),
                  times, lh, [(0, 4, -1, 0.0, 0)], [], 1,
-                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), 0,
+                 dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
                  st.ravel().copy(), rr.ravel()[:, None].copy(), dict(split=true_split, rate=true_rate))
     w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
     return w
@@ -97,7 +98,7 @@ def config2x16(spectrum_fn, n_grid=16, **kw):
     return w
 
 
-def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6):
+def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6, cpfit=True):
     """Two optimised bands, random starts (one batched simplex-vertex evaluation)."""
     inp = synth.psmc_pair(64, 65)
     band_truth = [(0, 4, true_split, 0.2, -1), (1, 10, true_split, 0.05, -1)]
@@ -106,9 +107,9 @@ def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6):
     jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
     rng = np.random.default_rng(seed)
     par = 10.0 ** rng.uniform(-3, 0, size=(n_start, 2))
-    w = Workload("config3: numT=128, two optimised bands, %d random starts, --cpfit" % n_start,
+    w = Workload("config3: numT=128, two optimised bands, %d random starts, %s" % (n_start, "--cpfit" if cpfit else "default fit"),
                  times, lh, [(0, 4, true_split, 0.1, 0), (1, 10, true_split, 0.1, 1)], [], 2,
-                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), 0,
+                 dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
                  np.full(n_start, float(true_split)), par, dict(split=true_split))
     w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
     return w
@@ -130,7 +131,7 @@ def config4(spectrum_fn, n_split=256, n_rep=1000, true_split=50, cpfit=False, se
     return w
 
 
-def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true_split=80, n_sites=10 ** 6):
+def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true_split=80, n_sites=10 ** 6, cpfit=True):
     """Ancient second genome (--sdate 40000) + --hetloss 0 0.1; split x band rate x pulse fraction."""
     inp = synth.psmc_pair(64, 64, sample_date=40000.0, units=mio.Units(hetloss2=0.1))
     sd = inp.sampleDateDiscr
@@ -143,9 +144,9 @@ def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true
     rates = np.logspace(-3, 0, n_rate)
     fr = np.linspace(0.0, 0.5, n_pulse)
     a, b, c = np.meshgrid(splits, rates, fr, indexing="ij")
-    w = Workload("config5: numT=128 sdate=40000 hetloss=(0,0.1), %dx%dx%d split x mi x pu grid, --cpfit" % (n_split, n_rate, n_pulse),
+    w = Workload("config5: numT=128 sdate=40000 hetloss=(0,0.1), %dx%dx%d split x mi x pu grid, %s" % (n_split, n_rate, n_pulse, "--cpfit" if cpfit else "default fit"),
                  times, lh, [(0, sd + 2, -1, 0.0, 0)], [(1, sd + 10, 0.0, 1)], 2,
-                 dict(cpfit=True, true_eps=False, smooth=True, unfolded=False), sd,
+                 dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), sd,
                  a.ravel().copy(), np.stack([b.ravel(), c.ravel()], axis=1), dict(split=true_split, sample_date=sd))
     w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
     return w

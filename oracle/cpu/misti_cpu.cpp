@@ -444,6 +444,27 @@ LsqResult trf_bounded(const Residual& fun, int N, double* x, double lb) {
     return res;
 }
 
+// ---- study hook: one ulp of noise in the pair chain's matrix exponential ------------------------------------------------
+// tests/golden/internal_noise.py re-runs the REFERENCE with scipy.linalg.expm as CorrectLambda.py:62 sees it returning every entry
+// moved by -1, 0 or +1 ulp at random: how well the reference's llh is determined by its own arithmetic.  The same study on this
+// restatement (misti_cpu_set_expm_noise; tools/uniform_spread.py) - a per-candidate generator, so results do not depend on threads.
+int g_noise_seed = -1;                           // < 0: off
+thread_local uint64_t t_noise_state = 0;
+inline uint64_t noise_next() {                   // splitmix64
+    uint64_t z = (t_noise_state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+inline void noise_apply(Mat& E) {
+    if (g_noise_seed < 0) return;
+    for (auto& v : E.a) {
+        const uint64_t k = noise_next() % 3;     // 0: as it is, 1: one ulp up, 2: one ulp down
+        if (k == 1) v = std::nextafter(v, INFINITY);
+        else if (k == 2) v = std::nextafter(v, -INFINITY);
+    }
+}
+
 // ------------------------------------------------------------------------- the pair chain (CorrectLambda.py) ----
 struct PairChain {
     double mu[2] = {0, 0}, lh[2] = {0, 0}, T = 0, mixtureTH = 0;
@@ -456,7 +477,13 @@ struct PairChain {
         M(2, 0) = 2 * mu[0]; M(2, 1) = 2 * mu[1]; M(2, 2) = -mu[0] - mu[1];
         return M;
     }
-    bool met(const double* l, Mat& E) const { Mat M = matrix(l); for (auto& v : M.a) v *= T; return expm(M, E); }   // MatrixExponent :58-62
+    bool met(const double* l, Mat& E) const {                             // MatrixExponent :58-62
+        Mat M = matrix(l);
+        for (auto& v : M.a) v *= T;
+        if (!expm(M, E)) return false;
+        noise_apply(E);
+        return true;
+    }
     double ect_one_pop(double lam) const { const double r = lam > 100 ? 0.0 : T / (std::exp(lam * T) - 1.0); return 1.0 / lam - r; }   // :67-72
     double ect_one_pop_tmp(double lam) const { const double pnc = std::exp(-lam * T); return 1.0 / lam - T / (1.0 / pnc - 1.0); }      // :74-77
     double ect_noncond(double lam) const { return (1 - std::exp(-lam * T) * (1 + lam * T)) / lam; }                                     // :79-80
@@ -795,6 +822,7 @@ int misti_cpu_eval(int numT, int sample_date, unsigned flags, double mixture_th,
     int used = 1;
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
     for (int64_t c = 0; c < n_cand; ++c) {
+        if (g_noise_seed >= 0) t_noise_state = (uint64_t)g_noise_seed * 0x100000001b3ull + (uint64_t)c * 0x9e3779b97f4a7c15ull + 1;
         status[c] = eval_candidate(m, split_time[c], n_param ? params + c * n_param : nullptr, jsfs, (int)n_rep, llk + c * n_rep,
                                    jafs ? jafs + 7 * c : nullptr, runaway ? runaway + c : nullptr);
     }
@@ -803,5 +831,9 @@ int misti_cpu_eval(int numT, int sample_date, unsigned flags, double mixture_th,
 #endif
     return used;
 }
+
+// seed >= 0: every following misti_cpu_eval moves each entry of the pair chain's expm by -1, 0 or +1 ulp (generator = seed x candidate);
+// seed < 0: off.  Process-wide; a study hook of the checker, never used on a timed or compared path.
+void misti_cpu_set_expm_noise(int seed) { g_noise_seed = seed; }
 
 }  // extern "C"

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Reference-run goldens for candidates of BASELINE's FULL-SIZE grids (needs /root/reference: build container only).
+
+The full-size parity tests (tests/test_gpu_fullsize.py, tools/fullsize_report.py) check every candidate of configs 2, 3 and 5 against
+the compiled CPU baseline.  The candidates that check puts OUTSIDE the contract, and an evenly spaced sample of the default-fit grids
+fixed before any result was looked at, are run here through /root/reference ITSELF:
+
+    python tests/golden/make_fullsize.py values  config5 12315 12667 ...      # one reference run each -> scratch/fullsize_values_<wl>.json
+    python tests/golden/make_fullsize.py study   config5 12315 ...            # + 64 input perturbations, 16 one-ulp-in-expm runs, 16
+                                                                              #   one-ulp-in-residual runs, solver trace -> golden_fullsize.json
+    python tests/golden/make_fullsize.py default                              # 48 candidates of config2 / config3 under the DEFAULT fit, evenly
+                                                                              #   spaced, 16 + 16 runs each + traces -> golden_default_fit.json
+
+`values` answers "who is right, the device or the checker" at 1.5 s per candidate; `study` is the depth camp_m148_c12 got in round 3
+(tests/golden/internal_noise.py) and decides whether a candidate lies inside clause 2 of the contract BY THE REFERENCE'S OWN MEASUREMENT.
+Workloads are rebuilt here with the oracle's truth spectrum; the dump of tools/fullsize_report.py (--dump) carries the data JSFS and rates
+the GPU box used, and the two are asserted equal."""
+import gzip
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+import warnings
+
+import numpy
+
+numpy.mat = numpy.asmatrix
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import make_golden as mg               # noqa: E402  (imports the reference)
+import internal_noise as inz           # noqa: E402
+import parity                          # noqa: E402
+
+N_INPUT, N_INTERNAL, N_RESIDUAL = 64, 16, 16
+DUMP = os.path.join(ROOT, "gpurun_out", "fs")
+
+
+def workload(spec):
+    from misti_amd import workloads
+    from oracle.batch import oracle_truth_spectrum
+    name, _, fit = spec.partition(":")
+    kw = {"cpfit": fit == "cpfit"} if fit else {}
+    w = getattr(workloads, name)(oracle_truth_spectrum, **kw)
+    p = os.path.join(DUMP, "fullsize_%s.npz" % spec.replace(":", "_"))
+    dump = numpy.load(p) if os.path.exists(p) else None
+    if dump is not None:
+        assert numpy.array_equal(dump["jsfs"], w.jsfs[0]) and numpy.array_equal(dump["lh"], numpy.array(w.lh)) and numpy.array_equal(dump["times"], numpy.array(w.times))
+    return w, dump
+
+
+def reference_args(w, idx):
+    """Candidate idx of workload w as the reference's constructor sees it."""
+    from oracle.batch import _mis_pus
+    par = [float(v) for v in w.params[idx]] if w.params is not None else []
+    split = float(w.split_time[idx])
+    split = int(split) if split == int(split) else split
+    end = int(split) + (1 if split % 1 else 0)
+    mis, pus = _mis_pus(w.bands, w.pulses, end, par)
+    kw = dict(smooth=bool(w.flags["smooth"]))
+    if w.flags["cpfit"]:
+        kw["cpfit"] = True
+    if w.flags["unfolded"]:
+        kw["unfolded"] = True
+    if w.flags["true_eps"]:
+        kw["trueEPS"] = True
+    if w.sample_date:
+        kw["sampleDate"] = int(w.sample_date)
+    order = [b[4] for b in w.bands if b[4] >= 0] + [b[3] for b in w.pulses if b[3] >= 0]
+    return list(w.times), [list(x) for x in w.lh], [float(v) for v in w.jsfs[0]], split, mis, pus, kw, [par[i] for i in order]
+
+
+_W = {}
+
+
+def _value_job(job):
+    spec, idx = job
+    w, _ = _W[spec]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = reference_args(w, idx)
+        rec = mg.run_reference(*a)
+    return idx, rec["llh"]
+
+
+def _study_job(job):
+    spec, idx, n_in, n_int, n_res, trace = job
+    w, _ = _W[spec]
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        times, lam, sfs, split, mis, pus, kw, params = reference_args(w, idx)
+        c = mg.case("%s_c%d" % (spec.replace(":", "_"), idx), times, lam, sfs, split, mis, pus, params, **kw)
+        o = c["out"]
+        if o["llh"] is not None:
+            _, o["spread"], o["pert_fail"], o["pert_llh"] = mg.perturbation_study(times, lam, sfs, split, mis, pus, kw, params, o["llh"], n_in)
+            o["sens"] = None if o["pert_fail"] else o["spread"] / parity.PERTURB
+            o["pert_kinds"] = n_in
+            i = c["in"]
+            vals = [inz.run(i, inz.NoisyLinalg(7000 + s)) for s in range(n_int)]
+            fin = [v for v in vals if v is not None]
+            o["internal_spread"] = max(abs(v - o["llh"]) / abs(o["llh"]) for v in fin) if fin else None
+            o["internal_fail"], o["internal_runs"], o["internal_llh"] = n_int - len(fin), n_int, vals
+            if n_res:
+                vals = [inz.run(i, None, inz.NoisyOptimize(9000 + s)) for s in range(n_res)]
+                fin = [v for v in vals if v is not None]
+                o["residual_spread"] = max(abs(v - o["llh"]) / abs(o["llh"]) for v in fin) if fin else None
+                o["residual_fail"], o["residual_runs"] = n_res - len(fin), n_res
+        o.pop("Pr", None)
+        tr = mg.traced(c) if (trace and o["llh"] is not None) else None
+    c["fullsize"] = {"workload": spec, "cand": int(idx)}
+    c["ref_seconds"] = round(time.time() - t0, 1)
+    return c, tr
+
+
+def pool_map(fn, jobs, procs):
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(1):
+        with mp.get_context("fork").Pool(procs) as pool:
+            for k, r in enumerate(pool.imap(fn, jobs)):
+                print("  %d / %d" % (k + 1, len(jobs)), file=sys.stderr, flush=True)
+                yield r
+
+
+def write_golden(path, cases, traces, note):
+    for c in cases:
+        c["in"] = dict(c["in"])
+    grids = mg.dedupe(cases)
+    json.dump({"generator": "tests/golden/make_fullsize.py", "scipy": "1.15.3", "numpy": "2.2.6", "note": note, "grids": grids, "cases": cases}, open(path, "w"))
+    if traces:
+        with gzip.open(path.replace(".json", "_traces.json.gz"), "wt") as f:
+            json.dump({"generator": "tests/golden/make_fullsize.py", "scipy": "1.15.3", "cases": traces}, f)
+
+
+def main():
+    mode = sys.argv[1]
+    procs = int(os.environ.get("PROCS", "6"))
+    if mode == "values":
+        spec = sys.argv[2]
+        idxs = [int(v) for v in sys.argv[3:]]
+        _W[spec] = workload(spec)
+        _, dump = _W[spec]
+        if not idxs:
+            idxs = sorted(set(int(v) for v in dump["outside"]) | set(int(v) for v in dump["mismatch"]))
+        out = {}
+        for idx, llh in pool_map(_value_job, [(spec, i) for i in idxs], procs):
+            rec = {"ref": llh}
+            if dump is not None:
+                h, b = float(dump["hip_llk"][idx]), float(dump["base_llk"][idx])
+                rec.update(hip=h if numpy.isfinite(h) else None, base=b if numpy.isfinite(b) else None, run=float(dump["run"][idx]))
+                if llh is not None and numpy.isfinite(h):
+                    rec["hip_rel"] = abs(h - llh) / abs(llh)
+                if llh is not None and numpy.isfinite(b):
+                    rec["base_rel"] = abs(b - llh) / abs(llh)
+            out[idx] = rec
+        os.makedirs(os.path.join(ROOT, "scratch"), exist_ok=True)
+        p = os.path.join(ROOT, "scratch", "fullsize_values_%s.json" % spec.replace(":", "_"))
+        json.dump(out, open(p, "w"), indent=0)
+        n_dev = sum(1 for r in out.values() if r.get("hip_rel", 1) > 1e-9)
+        print("%s: %d candidates through the reference; device beyond 1e-9 of the REFERENCE on %d, checker beyond 1e-9 on %d -> %s"
+              % (spec, len(out), n_dev, sum(1 for r in out.values() if r.get("base_rel", 0) > 1e-9), p))
+        return
+    if mode == "study":
+        # python make_fullsize.py study spec idx idx ... [spec2 idx ...]
+        jobs, spec = [], None
+        for a in sys.argv[2:]:
+            if a.lstrip("-").isdigit():
+                jobs.append((spec, int(a), N_INPUT, N_INTERNAL, N_RESIDUAL, True))
+            else:
+                spec = a
+                if spec not in _W:
+                    _W[spec] = workload(spec)
+        path = os.path.join(HERE, "golden_fullsize.json")
+        cases, traces = [], []
+        for c, tr in pool_map(_study_job, jobs, procs):
+            cases.append(c)
+            if tr:
+                traces.append(tr)
+        write_golden(path, cases, traces, "candidates of BASELINE's full-size grids that tools/fullsize_report.py (round 4, compiled baseline as checker) put outside the "
+                     "contract, run through /root/reference with %d input perturbations, %d one-ulp-in-expm and %d one-ulp-in-residual runs" % (N_INPUT, N_INTERNAL, N_RESIDUAL))
+        print("wrote %d cases -> %s" % (len(cases), path))
+        return
+    if mode == "default":
+        jobs = []
+        for spec, n in (("config2:default", 4096), ("config3:default", 16384)):
+            _W[spec] = workload(spec)
+            # 24 per grid, evenly spaced, fixed before any result was looked at; config 2's grid is split-major with 64 rates per split, so a stride
+            # that is not a multiple of 64 walks through splits and rates alike
+            idxs = [int(round((k + 0.5) * n / 24.0)) for k in range(24)]
+            jobs += [(spec, i, 16, 16, 0, True) for i in idxs]
+        path = os.path.join(HERE, "golden_default_fit.json")
+        cases, traces = [], []
+        for c, tr in pool_map(_study_job, jobs, procs):
+            cases.append(c)
+            if tr:
+                traces.append(tr)
+        write_golden(path, cases, traces, "48 candidates of BASELINE configs 2 and 3 under the reference's DEFAULT fit (MiSTI.py:86,213), evenly spaced, "
+                     "through /root/reference with 16 input perturbations and 16 one-ulp-in-expm runs each, with solver traces")
+        print("wrote %d cases -> %s" % (len(cases), path))
+        return
+    raise SystemExit("mode: values | study | default")
+
+
+if __name__ == "__main__":
+    main()

@@ -140,12 +140,15 @@ def implemented(kw):
 
 
 # ---- the contract at test time, against the compiled CPU baseline ----------------------------------------------------
-def baseline_contract(w, idx, hip_llk, hip_status, hip_jafs=None, rep=0, threads=16, kinds=8):
+def baseline_contract(w, idx, hip_llk, hip_status, hip_jafs=None, rep=0, threads=16, kinds=8, internal=8):
     """Per-candidate contract for the candidates `idx` of workload `w` (replicate `rep`), checked against the compiled CPU baseline
     (oracle/cpu/misti_cpu.cpp: the reference's algorithm restated, pinned on the reference's golden vectors): llk within
-    llk_tol, else within SELF_FACTOR x that candidate's own spread under `kinds` 2^-48 perturbations of the inputs -
-    computed here, only for the candidates that need it.  Returns a report dict; `outside` / `mismatch` are positions in idx."""
-    from oracle.cpu_baseline import cpu_eval
+    llk_tol, else within SELF_FACTOR x that candidate's own spread under `kinds` 2^-48 perturbations of the inputs and under
+    `internal` runs with one ulp of noise in the pair chain's matrix exponential (the contract's two measurements; the second one
+    since round 4: misti_cpu_set_expm_noise) - the same depth for every candidate that is not within llk_tol, computed here.
+    Returns a report dict; `outside` / `mismatch` are positions in idx."""
+    import ctypes
+    from oracle.cpu_baseline import cpu_eval, load as load_baseline
     idx = np.asarray(idx)
     split = w.split_time[idx]
     par = None if w.params is None else w.params[idx]
@@ -172,6 +175,17 @@ def baseline_contract(w, idx, hip_llk, hip_status, hip_jafs=None, rep=0, threads
             d = np.where(fin, np.abs(p_llk[:, 0] - c_llk[need, 0]), 0.0)
             spread[need] = np.maximum(spread[need], d)
             flips[need] |= (p_st == 0) != (c_st[need] == 0)
+        lib = load_baseline()
+        try:
+            for run in range(internal):
+                lib.misti_cpu_set_expm_noise(ctypes.c_int(7000 + run))
+                p_llk, _, p_st, _, _ = base(w.times, w.lh, need)
+                fin = (p_st == 0) & (c_st[need] == 0)
+                d = np.where(fin, np.abs(p_llk[:, 0] - c_llk[need, 0]), 0.0)
+                spread[need] = np.maximum(spread[need], d)
+                flips[need] |= (p_st == 0) != (c_st[need] == 0)
+        finally:
+            lib.misti_cpu_set_expm_noise(ctypes.c_int(-1))
     tight = both & (err <= tol)
     selfb = both & ~tight & (err <= SELF_FACTOR * spread)
     outside = both & ~tight & ~selfb

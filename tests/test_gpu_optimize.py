@@ -208,3 +208,38 @@ def test_basinhopping_equals_scipy(cfg3):
         assert -ref.fun == got["llh"][s] and ref.nfev == got["nfev"][s] and ref.minimization_failures == got["failures"][s], (s, ref.fun, ref.nfev)
         hops_taken += got["accepted"][s]
     assert hops_taken > 0                                    # the Metropolis test really accepted some hops
+
+
+def test_evaluation_budget_is_cut_per_evaluation_as_scipy_does(cfg3):
+    """maxfev: SciPy refuses the call that would exceed the budget and abandons the iteration in progress (nothing accepted, a shrink
+    applied up to the refused vertex, `iterations` not incremented: _minimize_neldermead's _MaxFuncCallError path).  Budgets 3 ... 25
+    cut the minimisation in every phase - inside the initial simplex, before the second point, inside a shrink; compared with
+    scipy.optimize.basinhopping(niter=0 and 3) on the GPU objective, whose result carries the minimisation's x, fun, nfev and failure."""
+    from scipy import optimize
+    import warnings
+    w, eng = cfg3
+    split = float(w.split_time[0])
+    S = 6
+    starts = w.params[:S]
+
+    def obj(mu):
+        if (np.asarray(mu) < 0).any():
+            return np.inf
+        v = float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+        return -v if np.isfinite(v) else np.inf
+    cut_seen = 0
+    for maxfev, niter in ((2, 0), (3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (9, 0), (12, 0), (16, 0), (25, 0), (8, 3), (13, 3)):
+        got = eng.basinhopping(starts, split, w.jsfs[0], rngs=[300 + s for s in range(S)], niter=niter, T=0.5, stepsize=0.05, interval=2,
+                               nm_maxiter=10 ** 6, nm_maxfev=maxfev)
+        for s in range(S if niter == 0 else 3):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = optimize.basinhopping(obj, starts[s], niter=niter, T=0.5, stepsize=0.05, interval=2,
+                                            minimizer_kwargs=dict(method="Nelder-Mead", options=dict(maxfev=maxfev, maxiter=10 ** 6)),
+                                            rng=np.random.default_rng(300 + s))
+            assert np.array_equal(ref.x, got["x"][s]), (maxfev, niter, s, ref.x, got["x"][s])
+            assert -ref.fun == got["llh"][s] and ref.nfev == got["nfev"][s], (maxfev, niter, s, ref.fun, got["llh"][s], ref.nfev, got["nfev"][s])
+            assert ref.minimization_failures == got["failures"][s]
+            assert got["nfev"][s] <= (niter + 1) * maxfev
+            cut_seen += got["failures"][s] > 0
+    assert cut_seen >= 20                                   # the budget really ran out

@@ -94,7 +94,12 @@ def main():
                     ref.append(out)
                     if k % 500 == 0:
                         print("oracle %d / %d" % (k, len(jobs)), file=sys.stderr, flush=True)
-        json.dump({"models": a.models, "seed": a.seed, "n": len(ref), "ref": ref}, open(a.make_ref, "w"))
+        if a.make_ref.endswith(".gz"):             # the compact committed fixture: [llk, status, rate x length] per candidate
+            import gzip
+            with gzip.open(a.make_ref, "wt") as f:
+                json.dump({"models": a.models, "seed": a.seed, "n": len(ref), "ref": [[r[0], r[2], r[3]] for r in ref]}, f)
+        else:
+            json.dump({"models": a.models, "seed": a.seed, "n": len(ref), "ref": ref}, open(a.make_ref, "w"))
         print("wrote", a.make_ref, len(ref), "candidates")
         return
     ref = load_ref(a.ref, a.models, a.seed, len(jobs))
