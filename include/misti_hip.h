@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MISTI_ABI_VERSION 3
+#define MISTI_ABI_VERSION 4
 
 /* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
 #define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */
@@ -203,7 +203,9 @@ int misti_last_diag(misti_ctx* ctx, int64_t n_cand, double* max_rate_x_len);
  *   x           [n_start][n_param]   best vertex per start
  *   llh         [n_start]            its log-likelihood (-inf if no vertex has a value)
  *   nit, nfev   [n_start] or NULL    SciPy's OptimizeResult.nit / .nfev
- *   status      [n_start] or NULL    0 converged (both tolerances), 2 iteration budget */
+ *   status      [n_start] or NULL    0 converged (both tolerances), 2 iteration budget (1: evaluation budget - only inside
+ *                                    misti_basinhopping, whose minimisations run with SciPy's default maxfev = 200 x n_param; the
+ *                                    budget is cut per evaluation as SciPy does: nfev never exceeds it) */
 int misti_nm_solve(misti_ctx* ctx, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
                    double xatol, double fatol, int32_t maxiter,
                    double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status);
@@ -236,6 +238,41 @@ int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
  * 4 + n_param points SciPy could ask for in an iteration go out as one engine batch and one kernel takes its decisions
  * from the values it would have asked for - one chain latency per iteration instead of three; nfev stays SciPy's count. */
 int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
+
+/* ---- several devices --------------------------------------------------------------------- */
+/* One model on a LIST of devices - 1, 2, 4 or 8 GPUs of a node from ONE process: one engine context and one host thread per
+ * entry (a device may be listed more than once: two contexts overlap their batches on it).  Replaces what the reference does
+ * with more than one processor: `parallel -j 20 ./MiSTI.py ... ::: st ... ::: mc ... >> res.out` (README.md:110-115) and the
+ * bash loops of test.bs/ (san_sar.bs.sh:29-36) - one OS process per grid point, results concatenated from stdout.
+ * Candidates are independent, so there is no exchange between devices during evaluation; what must not be split is a CHAIN:
+ * candidates with bitwise identical parameter vectors and band bounds share one lambda-correction chain,
+ * computed once per context that holds any of them.  misti_multi_eval_batch therefore deals whole chains to the contexts
+ * (round-robin in order of first appearance; a batch without parameters is one chain and is interleaved instead), runs
+ * misti_eval_batch on every context at the same time and writes every candidate's rows straight into the caller's buffers:
+ * the result is bit for bit that of misti_eval_batch on one device.  Same arguments and conventions as misti_eval_batch.
+ * (A process that keeps results on the devices runs one rank per GPU and gathers with RCCL instead: misti_amd/dist.py.) */
+typedef struct misti_multi misti_multi;
+int misti_create_multi(const misti_model_t* model, int n_dev, const int* devices, misti_multi** out);
+int misti_destroy_multi(misti_multi* m);
+int misti_multi_size(misti_multi* m);                                        /* contexts (= entries of the device list) */
+int misti_multi_context(misti_multi* m, int i, misti_ctx** ctx, int* device); /* the i-th context (borrowed) and its device; either may be NULL */
+int misti_multi_eval_batch(misti_multi* m, int64_t n_cand,
+                           const double* split_time, const double* params, const int32_t* band_bounds,
+                           int64_t n_rep, const double* jsfs,
+                           double* llk, double* jafs, double* lc, double* pr, int32_t* status);
+/* Shards of the last misti_multi_eval_batch: candidates and chains per context ([misti_multi_size] each; either may be NULL). */
+int misti_multi_last_shards(misti_multi* m, int64_t* n_cand, int64_t* n_chain);
+/* misti_nm_solve / misti_basinhopping with the starts dealt to the contexts in contiguous blocks, all contexts searching at the
+ * same time (BASELINE config 3: 16 384 starts -> 2 048 per GPU on a node).  Starts are independent searches and a start's
+ * trajectory does not depend on what else travels in its batches: results equal the single-device call's, start for start.
+ * Arguments as misti_nm_solve / misti_basinhopping (`uniforms` is indexed by start, so a block takes its slice). */
+int misti_multi_nm_solve(misti_multi* m, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                         double xatol, double fatol, int32_t maxiter,
+                         double* x, double* llh, int32_t* nit, int32_t* nfev, int32_t* status);
+int misti_multi_basinhopping(misti_multi* m, int64_t n_start, const double* starts, double split_time, const double* jsfs_row,
+                             int32_t niter, double T, double stepsize, int32_t interval, double target_accept_rate, double stepwise_factor,
+                             double xatol, double fatol, int32_t nm_maxiter, int64_t nm_maxfev, const double* uniforms,
+                             double* x, double* llh, int32_t* nfev, int32_t* failures, int32_t* accepted);
 
 /* ---- solver trace (parity diagnostics) ---------------------------------------- */
 /* The reference's corrected rates are DEFINED by where SciPy's trust-region iteration stops

@@ -21,7 +21,7 @@ STATUS_TEXT = {
     6: "Stiff interval: the contour solver (rate x length > 96) did not converge",
 }
 MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
-ABI_VERSION = 3
+ABI_VERSION = 4
 TRACE_MAX_CAND, TRACE_MAX_ITER = 64, 200
 
 
@@ -78,6 +78,18 @@ SYMBOLS = {
     "misti_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_kernel_times": (C.c_int, [C.c_void_p, _PD, C.POINTER(C.c_int64), C.c_int]),
     "misti_tables": (C.c_int, [_PI, _PI]),
+    "misti_create_multi": (C.c_int, [C.POINTER(Model), C.c_int, _PI, C.POINTER(C.c_void_p)]),
+    "misti_destroy_multi": (C.c_int, [C.c_void_p]),
+    "misti_multi_size": (C.c_int, [C.c_void_p]),
+    "misti_multi_context": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "misti_multi_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_multi_last_shards": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "misti_multi_nm_solve": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "misti_multi_basinhopping": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,
+                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -112,7 +124,10 @@ def load(build_if_missing=True):
     except ImportError:
         pass
     lib = C.CDLL(path)
-    experimental = bool(os.environ.get("MISTI_LIB"))
+    # MISTI_LIB alone keeps every check: an explicitly chosen build must still be THIS ABI (ctypes signatures of another version mean
+    # memory corruption, not an error).  Only the A/B tools (tools/ab_compare.py, tools/stamp_run.py), which load older builds on
+    # purpose and call nothing whose signature changed, set MISTI_LIB_AB=1 to relax them.
+    experimental = bool(os.environ.get("MISTI_LIB")) and os.environ.get("MISTI_LIB_AB") == "1"
     for name, (res, args) in SYMBOLS.items():
         try:
             fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol

@@ -17,6 +17,10 @@ and the GNU-parallel recipe of ``README.md:110-115``):
                               given split time follow each candidate's split
     --grid-mi K LO HI N       N log-spaced values for the K-th optimised parameter
     --all-bs                  evaluate every row of the JSFS file as a replicate
+    --gpus N                  the sweep on N GPUs of the node: this process starts N ranks (one per GPU, torch.distributed over
+                              RCCL), whole lambda-correction chains are dealt to the ranks, one all_gather, rank 0 prints
+    --devices 0,1,...         the sweep on a LIST of devices from this one process (misti_create_multi: one context and one host
+                              thread per entry)
 """
 from __future__ import annotations
 
@@ -29,7 +33,7 @@ from math import ceil
 import numpy as np
 
 from . import io as mio
-from .engine import Engine, MigrationInference
+from .engine import BatchResult, Engine, MigrationInference
 
 
 def build_parser():
@@ -62,7 +66,29 @@ def build_parser():
     p.add_argument("--grid-mi", nargs=4, action="append", default=[], metavar=("K", "LO", "HI", "N"),
                    help="log-spaced values for optimised parameter K")
     p.add_argument("--all-bs", action="store_true", help="evaluate every JSFS row as a bootstrap replicate")
+    p.add_argument("--gpus", type=int, default=1, help="grid mode: start this many ranks, one per GPU (replaces `parallel -j N ./MiSTI.py ...`)")
+    p.add_argument("--devices", type=str, default="", help="grid mode: comma-separated device list evaluated from this one process (misti_create_multi)")
     return p
+
+
+def _evaluator(a, inp, bands, pulses, k, device):
+    """The batch evaluator of grid mode: ``evaluate(split, params, rows)`` -> an object with ``llk[n][R]`` and ``status[n]``, and a
+    function closing it.  The HIP engine on ``device`` (``--devices``: the multi-device form).  MISTI_TEST_EVALUATOR=module:factory
+    replaces the engine by ``factory(times, lambdas, bands, pulses, n_param, flags, sample_date, mixture_th)``: the hook of the CPU
+    tests, which have no GPU (tests/test_dist_cpu.py runs the rank launch over gloo with the oracle behind it) - never set otherwise."""
+    flags = dict(cpfit=a.cpfit, true_eps=a.trueEPS, smooth=not a.nosmooth, unfolded=a.uf)
+    hook = os.environ.get("MISTI_TEST_EVALUATOR", "")
+    if hook:
+        import importlib
+        mod, fn = hook.split(":")
+        return getattr(importlib.import_module(mod), fn)(inp.times, inp.lambdas, bands, pulses, k, flags, inp.sampleDateDiscr, a.mth), lambda: None
+    if a.devices:
+        from .engine import MultiEngine
+        e = MultiEngine(inp.times, inp.lambdas, bands, pulses, n_param=k, sample_date=inp.sampleDateDiscr, mixture_th=a.mth,
+                        devices=[int(d) for d in a.devices.split(",")], **flags)
+    else:
+        e = Engine(inp.times, inp.lambdas, bands, pulses, n_param=k, sample_date=inp.sampleDateDiscr, mixture_th=a.mth, device=device, **flags)
+    return e.evaluate, e.close
 
 
 def grid_mode(a, inp, rows):
@@ -96,11 +122,27 @@ def grid_mode(a, inp, rows):
     split = mesh[0].ravel()
     params = np.stack([m.ravel() for m in mesh[1:]], axis=1) if k else None
     data = np.array(rows if a.all_bs else [rows[a.bsMode] if a.bsMode >= 0 else np.sum(rows, axis=0)], dtype=float)
+    # --gpus N: this process is one of N ranks (main() started them); whole chains per rank, one all_gather, rank 0 prints
+    from . import dist as mdist
+    rank, local, world = mdist.init_from_env()
     t0 = time.time()
-    with Engine(inp.times, inp.lambdas, bands, pulses, n_param=k, cpfit=a.cpfit, true_eps=a.trueEPS, smooth=not a.nosmooth,
-                unfolded=a.uf, sample_date=inp.sampleDateDiscr, mixture_th=a.mth, device=a.device) as e:
-        res = e.evaluate(split, params, data)
+    evaluate, close = _evaluator(a, inp, bands, pulses, k, local if world > 1 else a.device)
+    try:
+        if world > 1:
+            llk, status = mdist.evaluate_sharded(evaluate, split, params, data, by_chain=True, with_status=True)
+            res = BatchResult(llk.cpu().numpy(), None, status.cpu().numpy())
+        else:
+            res = evaluate(split, params, data)
+    finally:
+        close()
     dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+        if rank != 0:
+            return 0
+        print("Sharded over %d ranks (whole chains per rank; one all_gather of %d x %d log-likelihoods)" % (world, len(split), data.shape[0]))
     for c in range(len(split)):
         pstr = "" if params is None else "\t".join("%.6g" % v for v in params[c])
         for r in range(data.shape[0]):
@@ -124,6 +166,21 @@ def grid_mode(a, inp, rows):
 def main(argv=None):
     t0 = time.time()
     a = build_parser().parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not (a.grid_st or a.grid_mi or a.all_bs):
+            print("--gpus applies to the batched sweep (--grid-st / --grid-mi / --all-bs); a single model runs on one GPU", file=sys.stderr)
+        else:
+            # Start the ranks as CHILD processes and pass rank 0's output through.  This process has not imported torch or touched
+            # HIP and never does (a process that has initialised the GPU must not be forked or replaced); the reference's way of
+            # using N processors is `parallel -j N ./MiSTI.py ... >> res.out` (/root/reference/README.md:110-115).
+            from . import dist as mdist
+            code, out = mdist.launch_ranks(a.gpus, list(sys.argv[1:] if argv is None else argv), module="misti_amd.cli")
+            sys.stdout.write(out)
+            sys.stdout.flush()
+            return code
+    quiet = int(os.environ.get("RANK", "0")) != 0           # a rank other than 0 of a --gpus run: it computes, rank 0 reports
+    if quiet:
+        sys.stdout = open(os.devnull, "w")
     units = mio.Units.from_file(a.funits)
     print(units.describe())
     if a.hetloss is not None:

@@ -448,6 +448,9 @@ int misti_abi_version(void) { return MISTI_ABI_VERSION; }
 
 const char* misti_last_error(void) { return g_err.c_str(); }
 
+// internal (misti_multi.cpp): make `msg` the calling thread's last error; returns `code`
+int misti_set_error_(int code, const char* msg) { return fail(code, "%s", msg ? msg : ""); }
+
 int misti_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -688,8 +691,36 @@ int misti_argmax_dev(misti_ctx* c, int64_t n_cand, int64_t n_rep, const double* 
     return 0;
 }
 
+}  // extern "C"
+
+namespace {
+int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
+                    double* llk, double* jafs, double* lc, double* pr, int32_t* status);
+}
+
+extern "C" {
+
 int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
                      double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
+    const int r = eval_batch_host(c, n_cand, split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status);
+    // An error between the first asynchronous copy and the final wait leaves DMAs reading the context's pinned input block or
+    // writing its pinned output block: the next call would overwrite what they read.  Drain the stream before reporting.
+    if (r != 0 && c) {
+        const std::string why = g_err;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        g_err = why;
+    }
+    return r;
+}
+
+}  // extern "C"
+
+namespace {
+
+int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
+                    double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
@@ -759,6 +790,10 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
     for (int i = 0; i < n_back; ++i) std::memcpy(back[i].user, hout + back[i].off, back[i].bytes);
     return 0;
 }
+
+}  // namespace
+
+extern "C" {
 
 int misti_forward_rates_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, int hold_mu,
                             double* d_lh, double* d_pr, int32_t* d_status) {

@@ -103,7 +103,143 @@ def gather_rows(local, n_total, rank, world, interleave=True, group=None):
     return out
 
 
-def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=None, device=None, by_chain=False):
+def init_from_env(backend=None):
+    """Join the process group a launcher (``launch_ranks``, torchrun) prepared: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment.  Backend: ``nccl`` (= RCCL over xGMI) when this rank has a GPU, else ``gloo`` (the CPU tests); the rank's GPU is
+    LOCAL_RANK.  Returns (rank, local_rank, world); a no-op returning (0, 0, 1) without WORLD_SIZE."""
+    rank, local, world = env_rank()
+    if "WORLD_SIZE" not in os.environ:
+        return 0, 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if backend is None:
+            backend = os.environ.get("MISTI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def launch_ranks(n, argv, module=None, script=None, port=0, cwd=None):
+    """Start ``n`` ranks of ``python -m <module> argv`` (or ``python <script> argv``) as CHILD processes with
+    ``torch.distributed.run`` (one per GPU, rendezvous on 127.0.0.1) and return (exit code, stdout of the ranks).  The calling
+    process must not have touched the GPU and never does: a process that has initialised HIP must not be forked or replaced.
+    The reference's counterpart is ``parallel -j N`` over OS processes (``/root/reference/README.md:110-115``)."""
+    import socket
+    import subprocess
+    import sys
+    if not port:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += ["-m", module] if module else [script]
+    cmd += list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, cwd=cwd)
+    return r.returncode, r.stdout.decode(errors="replace")
+
+
+def block_bounds(n, world):
+    """Contiguous blocks of starts / replicates: rank r owns [lo[r], lo[r + 1]) (as misti_multi_nm_solve deals them)."""
+    return [n * r // world for r in range(world + 1)]
+
+
+def gather_blocks(local, n_total, rank, world, group=None):
+    """All-gather the row blocks of ``block_bounds`` (unequal by at most one row) back into order: ``[n_total, ...]`` on every rank."""
+    import torch
+    import torch.distributed as dist
+    lo = block_bounds(n_total, world)
+    if world == 1:
+        return local
+    per = max(lo[r + 1] - lo[r] for r in range(world))
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    flat = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, pad, group=group)
+    parts = flat.view((world, per) + tuple(local.shape[1:]))
+    return torch.cat([parts[r, : lo[r + 1] - lo[r]] for r in range(world)], dim=0)
+
+
+def _group_state(group=None):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return 0, 1, None
+    return dist.get_rank(group), dist.get_world_size(group), dist.get_backend(group)
+
+
+def search_sharded(search, starts, keys, group=None, device=None, **per_start):
+    """Independent searches (Nelder-Mead or basin-hopping starts: BASELINE config 3) over the ranks of the process group: rank r
+    runs ``search(starts[block r], **{k: v[block r]})`` - ``Engine.nm_solve`` / ``Engine.basinhopping`` bound to their other
+    arguments; ``per_start`` holds arguments indexed by start (basin hopping's ``rngs``) - and ONE all_gather returns, on every rank,
+    the dict of per-start arrays ``keys`` in start order.  A start's trajectory does not depend on what else travels in its batches,
+    so the result equals the single-device call's.  Scalars of the per-rank result (work counters) are dropped."""
+    import torch
+    rank, world, backend = _group_state(group)
+    starts = np.atleast_2d(np.asarray(starts, dtype=np.float64))
+    S = starts.shape[0]
+    lo = block_bounds(S, world)
+    a, b = lo[rank], lo[rank + 1]
+    kw = {k: v[a:b] for k, v in per_start.items()}
+    res = search(starts[a:b], **kw) if b > a else {k: np.zeros((0,) + ((starts.shape[1],) if k == "x" else ())) for k in keys}
+    if world == 1:
+        return {k: np.asarray(res[k]) for k in keys}
+    if device is None and backend == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    cols, widths = [], []
+    for k in keys:                                     # one collective for all keys: a float64 table [block, sum of widths]
+        v = np.asarray(res[k], dtype=np.float64).reshape(b - a, -1)
+        cols.append(v)
+        widths.append(v.shape[1])
+    table = torch.as_tensor(np.concatenate(cols, axis=1) if cols else np.zeros((b - a, 0)))
+    if device is not None:
+        table = table.to(device)
+    full = gather_blocks(table, S, rank, world, group).cpu().numpy()
+    out, c = {}, 0
+    for k, wd in zip(keys, widths):
+        v = full[:, c:c + wd]
+        c += wd
+        out[k] = v if k == "x" else v[:, 0]
+        if k in ("nit", "nfev", "status", "failures", "accepted"):
+            out[k] = out[k].astype(np.int32)
+    return out
+
+
+def best_per_replicate(llk):
+    """Per column (replicate) of ``llk[n_cand][n_rep]`` the row with the largest value; -inf and NaN never win, ties go to the
+    lowest index, -1 where no candidate has a value (what ``misti_argmax_dev`` computes on the device)."""
+    llk = getattr(llk, "llk", llk)
+    llk = np.asarray(llk.cpu() if hasattr(llk, "cpu") else llk, dtype=np.float64)
+    masked = np.where(np.isfinite(llk), llk, -np.inf)
+    return np.where(np.isfinite(masked.max(axis=0)), masked.argmax(axis=0), -1).astype(np.int64)
+
+
+def bootstrap_sharded(best_of_block, n_rep, group=None, device=None):
+    """A bootstrap scan (BASELINE config 4: split scan x 1 000 replicates) over the ranks: the REPLICATES are dealt out in contiguous
+    blocks - rank r scans every split value against its block of JSFS rows (the spectra are recomputed per rank: they are one
+    chain and cheap; the replicate epilogue and the arg-max are what is shared out) - and one all_gather of the per-replicate
+    winning index returns ``best[n_rep]`` on every rank.  ``best_of_block(a, b)`` -> winning candidate index for replicates
+    a .. b-1 (``optimize._scan_best`` on the rank's GPU; ``best_per_replicate`` of a host table in the CPU tests)."""
+    import torch
+    rank, world, backend = _group_state(group)
+    lo = block_bounds(int(n_rep), world)
+    a, b = lo[rank], lo[rank + 1]
+    best = np.asarray(best_of_block(a, b), dtype=np.int64) if b > a else np.zeros(0, dtype=np.int64)
+    if world == 1:
+        return best
+    if device is None and backend == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.as_tensor(best)
+    if device is not None:
+        t = t.to(device)
+    return gather_blocks(t, int(n_rep), rank, world, group).cpu().numpy()
+
+
+def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=None, device=None, by_chain=False, with_status=False):
     """Shard candidates over the ranks of the default process group and gather ``llk``.
 
     ``evaluate(split[n_loc], params[n_loc, P] or None, jsfs[R, 8])`` is the per-rank evaluator: it returns
@@ -111,7 +247,8 @@ def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=
     ``Engine.evaluate`` (a ``BatchResult``); the oracle in the CPU tests.  With the nccl backend (RCCL) the
     gathered tensor must live on the rank's GPU: ``device`` defaults to the current CUDA device there.
     ``by_chain=True`` deals whole chains to the ranks instead of interleaving candidates (``chain_shards``).
-    Returns ``llk[n_total, R]`` in candidate order on every rank.
+    Returns ``llk[n_total, R]`` in candidate order on every rank; with ``with_status=True`` (the evaluator's result must carry
+    ``status``) the per-candidate status travels in the same collective and ``(llk, status[n_total])`` is returned.
     """
     import torch
     import torch.distributed as dist
@@ -123,13 +260,17 @@ def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=
     shards = chain_shards(params, n, world) if by_chain else None      # whole chains per rank (see chain_shards)
     idx = shards[rank] if by_chain else shard_indices(n, rank, world, interleave)
     p_loc = None if params is None else np.asarray(params, dtype=np.float64)[idx]
-    llk = evaluate(split_time[idx], p_loc, jsfs)
-    llk = getattr(llk, "llk", llk)                       # a BatchResult
+    res = evaluate(split_time[idx], p_loc, jsfs)
+    llk = getattr(res, "llk", res)                       # a BatchResult
     llk = torch.as_tensor(llk, dtype=torch.float64)
+    if with_status:                                      # one collective: the status rides as an extra column
+        st = torch.as_tensor(np.asarray(res.status), dtype=torch.float64).reshape(-1, 1)
+        llk = torch.cat([llk.reshape(st.shape[0], -1), st], dim=1)
     if device is None and dist.is_initialized() and dist.get_backend(group) == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
     if device is not None:
         llk = llk.to(device)
-    if by_chain:
-        return gather_shards(llk, shards, rank, world, group)
-    return gather_rows(llk, n, rank, world, interleave, group)
+    out = gather_shards(llk, shards, rank, world, group) if by_chain else gather_rows(llk, n, rank, world, interleave, group)
+    if with_status:
+        return out[:, :-1], out[:, -1].to(torch.int32)
+    return out

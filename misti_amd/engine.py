@@ -238,14 +238,7 @@ class Engine:
         st = _f64(starts, (-1, self.n_param))
         S, N = st.shape
         row = _f64(jsfs_row, (8,))
-        gens = [g if isinstance(g, np.random.Generator) else np.random.default_rng(g) for g in rngs]
-        if len(gens) != S:
-            raise ValueError("one generator (or seed) per start")
-        uni = np.empty((S, int(niter), N + 1))
-        for s_, g in enumerate(gens):
-            for h in range(int(niter)):
-                uni[s_, h, :N] = g.random(N)                 # RandomDisplacement: rng.uniform(-stepsize, stepsize, shape)
-                uni[s_, h, N] = g.random()                   # Metropolis: rng.uniform()
+        uni = draw_uniforms(rngs, S, int(niter), N)
         x = np.empty((S, N))
         llh = np.empty(S)
         nfev, failures, accepted = (np.empty(S, dtype=np.int32) for _ in range(3))
@@ -292,6 +285,135 @@ class Engine:
 
 
 # ------------------------------------------------------------------------------
+class MultiEngine:
+    """One model on a LIST of devices from one process (``misti_create_multi`` ... ``misti_destroy_multi``): what a node's 1, 2, 4
+    or 8 GPUs are to a caller of the C ABI - the reference's counterpart is ``parallel -j 20 ./MiSTI.py ...``
+    (``/root/reference/README.md:110-115``).  Same constructor as ``Engine`` with ``devices`` (a list; an entry may repeat) in
+    place of ``device``.  ``evaluate`` deals whole lambda-correction chains to the devices and returns exactly what ``Engine.evaluate``
+    returns; ``nm_solve`` / ``basinhopping`` deal contiguous blocks of starts.  Nothing here falls back to fewer devices: a
+    device that cannot be opened fails the constructor."""
+
+    def __init__(self, times, lh, bands=(), pulses=(), n_param=0, cpfit=False, true_eps=False, smooth=False,
+                 unfolded=False, sample_date=0, mixture_th=0.0, devices=(0,)):
+        self._m = C.c_void_p()
+        self._lib = _lib.load()
+        times = _f64(times)
+        lh = _f64(lh)
+        self.numT = int(lh.shape[0])
+        if lh.ndim != 2 or lh.shape[1] != 2 or times.shape != (self.numT - 1,):
+            raise ValueError("times must have numT-1 entries and lh shape [numT][2]")
+        self.n_param = int(n_param)
+        self.flags = (CPFIT if cpfit else 0) | (TRUE_EPS if true_eps else 0) | (SMOOTH if smooth else 0) | (UNFOLDED if unfolded else 0)
+        self.unfolded = bool(unfolded)
+        bands, pulses = list(bands), list(pulses)
+        self.n_band = len(bands)
+        b_arr = (_lib.Band * max(1, len(bands)))()
+        for i, (pop, start, end, value, param) in enumerate(bands):
+            b_arr[i] = _lib.Band(int(pop), int(start), int(end), int(param), float(value))
+        p_arr = (_lib.Pulse * max(1, len(pulses)))()
+        for i, (pop, time, value, param) in enumerate(pulses):
+            p_arr[i] = _lib.Pulse(int(pop), int(time), int(param), 0, float(value))
+        m = _lib.Model(self.numT, int(sample_date), self.flags, len(bands), len(pulses), self.n_param, float(mixture_th),
+                       times.ctypes.data_as(C.POINTER(C.c_double)), lh.ctypes.data_as(C.POINTER(C.c_double)), b_arr, p_arr)
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int32 * max(1, len(self.devices)))(*self.devices)
+        h = C.c_void_p()
+        _lib.check(self._lib.misti_create_multi(C.byref(m), len(self.devices), dev, C.byref(h)))
+        self._m = h
+        self._pid = os.getpid()
+
+    def close(self):
+        if getattr(self, "_m", None) is not None and self._m:
+            if getattr(self, "_pid", None) == os.getpid():
+                self._lib.misti_destroy_multi(self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def evaluate(self, split_time, params=None, jsfs=None, want_lc=False, want_pr=False, band_bounds=None):
+        """``misti_multi_eval_batch``: as ``Engine.evaluate`` (``runaway`` is not collected across devices: None)."""
+        split = _f64(np.atleast_1d(split_time))
+        n = split.shape[0]
+        P = self.n_param
+        par = _f64(params, (n, P)) if P else None
+        rows = _f64(jsfs, (-1, 8)) if jsfs is not None and len(jsfs) else np.zeros((0, 8))
+        R = rows.shape[0]
+        llk = np.empty((n, R))
+        jafs = np.empty((n, 7))
+        status = np.empty(n, dtype=np.int32)
+        lc = np.empty((n, self.numT + 1, 2)) if want_lc else None
+        pr = np.empty((n, self.numT + 2, 6)) if want_pr else None
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+        bb = None
+        if band_bounds is not None and self.n_band:
+            bb = np.ascontiguousarray(band_bounds, dtype=np.int32).reshape(n, self.n_band, 2)
+        _lib.check(self._lib.misti_multi_eval_batch(self._m, n, ptr(split), ptr(par), ptr(bb), R, ptr(rows), ptr(llk), ptr(jafs),
+                                                    ptr(lc), ptr(pr), ptr(status)))
+        return BatchResult(llk, jafs, status, lc, pr, None)
+
+    def last_shards(self):
+        """(candidates per context, chains per context) of the last ``evaluate``."""
+        D = len(self.devices)
+        a, b = (C.c_int64 * D)(), (C.c_int64 * D)()
+        _lib.check(self._lib.misti_multi_last_shards(self._m, a, b))
+        return list(a), list(b)
+
+    def nm_solve(self, starts, split_time, jsfs_row, tol=1e-4, maxiter=1000):
+        """``misti_multi_nm_solve``: ``Engine.nm_solve`` with the starts dealt to the devices in contiguous blocks."""
+        st = _f64(starts, (-1, self.n_param))
+        S = st.shape[0]
+        row = _f64(jsfs_row, (8,))
+        x = np.empty((S, self.n_param))
+        llh = np.empty(S)
+        nit, nfev, status = (np.empty(S, dtype=np.int32) for _ in range(3))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.misti_multi_nm_solve(self._m, S, ptr(st), float(split_time), ptr(row), float(tol), float(tol), int(maxiter),
+                                                  ptr(x), ptr(llh), ptr(nit), ptr(nfev), ptr(status)))
+        return dict(x=x, llh=llh, nit=nit, nfev=nfev, status=status)
+
+    def basinhopping(self, starts, split_time, jsfs_row, rngs, niter=100, T=0.5, stepsize=0.5, interval=50, target_accept_rate=0.5,
+                     stepwise_factor=0.9, xatol=1e-4, fatol=1e-4, nm_maxiter=None, nm_maxfev=None):
+        """``misti_multi_basinhopping``: ``Engine.basinhopping`` with the starts dealt to the devices in contiguous blocks."""
+        st = _f64(starts, (-1, self.n_param))
+        S, N = st.shape
+        row = _f64(jsfs_row, (8,))
+        uni = draw_uniforms(rngs, S, int(niter), N)
+        x = np.empty((S, N))
+        llh = np.empty(S)
+        nfev, failures, accepted = (np.empty(S, dtype=np.int32) for _ in range(3))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.misti_multi_basinhopping(self._m, S, ptr(st), float(split_time), ptr(row), int(niter), float(T), float(stepsize), int(interval),
+                                                      float(target_accept_rate), float(stepwise_factor), float(xatol), float(fatol),
+                                                      int(nm_maxiter if nm_maxiter is not None else 200 * N), int(nm_maxfev if nm_maxfev is not None else 200 * N),
+                                                      ptr(uni), ptr(x), ptr(llh), ptr(nfev), ptr(failures), ptr(accepted)))
+        return dict(x=x, llh=llh, nfev=nfev, failures=failures, accepted=accepted)
+
+
+def draw_uniforms(rngs, S, niter, N):
+    """The uniforms SciPy's basin hopping would draw from start s's generator, in its order: per hop N for the displacement
+    (RandomDisplacement: rng.uniform(-stepsize, stepsize, shape)), then one for the Metropolis test.  ``rngs``: one
+    ``numpy.random.Generator`` or seed per start."""
+    gens = [g if isinstance(g, np.random.Generator) else np.random.default_rng(g) for g in rngs]
+    if len(gens) != S:
+        raise ValueError("one generator (or seed) per start")
+    uni = np.empty((S, niter, N + 1))
+    for s_, g in enumerate(gens):
+        for h in range(niter):
+            uni[s_, h, :N] = g.random(N)
+            uni[s_, h, N] = g.random()
+    return uni
+
+
 def _classes(v, unfolded):
     """The spectrum classes the likelihood distinguishes: all 7, or folded pairs 0+6, 1+5, 2+4 and 3 (:217-227, :600-609)."""
     return list(v) if unfolded else [v[0] + v[6], v[1] + v[5], v[2] + v[4], v[3]]

@@ -141,13 +141,42 @@ def solve_batched(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
     return r.x, -r.fun, r
 
 
-def solve_batched_dev(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
+def _world(group=None):
+    """Ranks of the process group this process belongs to (1 without torch.distributed or before it is initialised)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 1
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def solve_batched_dev(engine, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000, group=None):
     """``solve_batched`` with the simplices resident on the device (``misti_nm_solve``): no host round trip per
     iteration - per iteration three engine batches and four one-thread-per-start kernels on the engine's stream.
     Same decisions as SciPy's Nelder-Mead, hence the same result as ``solve_batched`` / ``MigrationInference.Solve``.
+    Inside a process group (one rank per GPU: ``misti_amd.dist.init_from_env``) the starts are dealt to the ranks in contiguous
+    blocks, every rank searches its block on its own GPU and one all_gather returns all starts on every rank
+    (``dist.search_sharded``) - BASELINE config 3's 16 384 starts are 2 048 per GPU on a node; results are those of one device.
     Returns (params[S, P], llh[S], dict with nit, nfev, status)."""
+    if _world(group) > 1:
+        from . import dist as mdist
+        r = mdist.search_sharded(lambda st: engine.nm_solve(st, split_time, jsfs_row, tol=tol, maxiter=maxiter), starts,
+                                 ("x", "llh", "nit", "nfev", "status"), group=group)
+        return r["x"], r["llh"], r
     r = engine.nm_solve(starts, split_time, jsfs_row, tol=tol, maxiter=maxiter)
     return r["x"], r["llh"], r
+
+
+def basinhopping_dev(engine, split_time, starts, jsfs_row, rngs, group=None, **kw):
+    """The reference's global search (``MigrationInference.Solve(globalOpt=True)``, ``/root/reference/MigrationInference.py:723-725``)
+    from every row of ``starts`` (``Engine.basinhopping``: SciPy's runner step for step); inside a process group the starts - and
+    their generators ``rngs`` - are dealt to the ranks in contiguous blocks and gathered once (``dist.search_sharded``).
+    Returns dict(x, llh, nfev, failures, accepted)."""
+    if _world(group) > 1:
+        from . import dist as mdist
+        return mdist.search_sharded(lambda st, rngs: engine.basinhopping(st, split_time, jsfs_row, rngs, **kw), starts,
+                                    ("x", "llh", "nfev", "failures", "accepted"), group=group, rngs=list(rngs))
+    return engine.basinhopping(starts, split_time, jsfs_row, rngs, **kw)
 
 
 def solve_grouped_dev(engines, split_time, starts, jsfs_row, tol=1e-4, maxiter=1000):
@@ -199,13 +228,35 @@ def bootstrap_split_interval(llk, split_values, level=0.95):
     return mean, (mean - half, mean + half), best
 
 
-def bootstrap_scan_dev(engine, split_values, jsfs_rows, params=None, level=0.95):
+def _t_interval(b, level):
+    from scipy import stats
+    m = b.size
+    mean, sd = b.mean(), b.std(ddof=1) if m > 1 else 0.0
+    half = stats.t.ppf(0.5 + level / 2, m - 1) * sd / np.sqrt(m) if m > 1 else 0.0
+    return mean, (mean - half, mean + half), b
+
+
+def bootstrap_scan_dev(engine, split_values, jsfs_rows, params=None, level=0.95, group=None):
     """A bootstrap scan that keeps the [n_split x n_rep] likelihood table on the device: one
     ``misti_eval_batch_dev`` over the split values x all replicates, then ``misti_argmax_dev`` per
     replicate; only the n_rep winning indices come back.  Returns what ``bootstrap_split_interval``
-    returns (mean, interval, per-replicate best split)."""
+    returns (mean, interval, per-replicate best split).  Inside a process group the REPLICATES are dealt to the ranks in
+    contiguous blocks (BASELINE config 4: 1 000 replicates = 125 per GPU on a node), each rank scans its block on its own GPU and
+    one all_gather of the winning indices follows (``dist.bootstrap_sharded``)."""
+    rows = np.asarray(jsfs_rows, dtype=float).reshape(-1, 8)
+    if _world(group) > 1:
+        from . import dist as mdist
+        idx = mdist.bootstrap_sharded(lambda a, b: _scan_best(engine, split_values, rows[a:b], params), rows.shape[0], group=group)
+    else:
+        idx = _scan_best(engine, split_values, rows, params)
+    if (idx < 0).any():
+        raise ValueError("a replicate has no finite likelihood over the scan")
+    return _t_interval(np.asarray(split_values, dtype=float)[idx], level)
+
+
+def _scan_best(engine, split_values, jsfs_rows, params=None):
+    """Per replicate the index of the best split value, reduced on the device (misti_eval_batch_dev + misti_argmax_dev)."""
     import torch
-    from scipy import stats
     dev = torch.device("cuda", engine.device)
     split = torch.as_tensor(np.asarray(split_values, dtype=float), device=dev)
     rows = torch.as_tensor(np.asarray(jsfs_rows, dtype=float).reshape(-1, 8), device=dev).contiguous()
@@ -219,11 +270,4 @@ def bootstrap_scan_dev(engine, split_values, jsfs_rows, params=None, level=0.95)
     engine.evaluate_dev(n, split.data_ptr(), par.data_ptr() if par is not None else 0, R, rows.data_ptr(), llk.data_ptr())
     engine.argmax_dev(n, R, llk.data_ptr(), best.data_ptr())
     engine.sync()
-    idx = best.cpu().numpy()
-    if (idx < 0).any():
-        raise ValueError("a replicate has no finite likelihood over the scan")
-    b = np.asarray(split_values, dtype=float)[idx]
-    m = b.size
-    mean, sd = b.mean(), b.std(ddof=1) if m > 1 else 0.0
-    half = stats.t.ppf(0.5 + level / 2, m - 1) * sd / np.sqrt(m) if m > 1 else 0.0
-    return mean, (mean - half, mean + half), b
+    return best.cpu().numpy().astype(np.int64)

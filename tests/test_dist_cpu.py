@@ -186,3 +186,127 @@ def test_chain_shards_partition_and_balance():
             assert len(s) == 5 * len(keys)
         assert max(len(s) for s in sh) - min(len(s) for s in sh) <= 5
     assert [len(s) for s in chain_shards(None, 10, 3)] == [4, 3, 3]
+
+
+# ---- round 4: the product entry points that use more than one GPU, rehearsed over gloo -----------------------------------------
+def _cli_fixture(tmp_path):
+    import json
+    from conftest import GOLDEN
+    cli = json.load(open(os.path.join(GOLDEN, "golden_host.json")))["cli"]
+    for name, key in (("g1.psmc", "psmc1"), ("g2.psmc", "psmc2"), ("data.sfs", "jsfs"), ("setunits.txt", "units")):
+        (tmp_path / name).write_text(cli[key])
+    return ["g1.psmc", "g2.psmc", "data.sfs", "20", "-wd", str(tmp_path), "--funits", str(tmp_path / "setunits.txt"), "--cpfit",
+            "-mi", "1", "2", "20", "0.1", "1", "--grid-st", "18", "21", "--grid-mi", "0", "0.05", "0.4", "3", "--all-bs"]
+
+
+def test_cli_gpus_starts_its_own_ranks_and_prints_the_unsharded_sweep(tmp_path):
+    """`python -m misti_amd.cli ... --grid-st --grid-mi --all-bs --gpus 2`: the process starts two ranks (torch.distributed.run over
+    gloo here, RCCL on a node), whole chains are dealt to them, rank 0 prints - the same lines as the one-process sweep.  The oracle
+    stands in for the engine (MISTI_TEST_EVALUATOR: no GPU here); the parent never imports torch."""
+    import subprocess
+    args = _cli_fixture(tmp_path)
+    env = dict(os.environ, MISTI_TEST_EVALUATOR="cli_oracle_hook:make", MISTI_DIST_BACKEND="gloo", PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    one = subprocess.run([sys.executable, "-m", "misti_amd.cli"] + args, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-X", "importtime", "-m", "misti_amd.cli"] + args + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    rows = lambda text: [l for l in text.splitlines() if l.startswith("bs_id =") or l.startswith("best:") or l.startswith("bootstrap:")]
+    assert len(rows(one.stdout)) == 4 * 3 * 5 + 2 and rows(two.stdout) == rows(one.stdout)
+    assert "Sharded over 2 ranks" in two.stdout and "Sharded" not in one.stdout
+    parent_imports = [l for l in two.stderr.splitlines() if l.startswith("import time:")]
+    assert parent_imports and not any(l.rstrip().endswith(" torch") for l in parent_imports)      # the launching process stays off torch / HIP
+
+
+def test_cli_gpus_without_a_gpu_and_without_the_hook_fails_loudly(tmp_path):
+    """No CPU fallback behind --gpus either: every rank needs its GPU."""
+    import subprocess
+    args = _cli_fixture(tmp_path)
+    env = dict(os.environ, MISTI_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+    env.pop("MISTI_TEST_EVALUATOR", None)
+    r = subprocess.run([sys.executable, "-m", "misti_amd.cli"] + args + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode != 0 and "bs_id =" not in r.stdout
+
+
+class StubSearchEngine:
+    """Engine-shaped object whose nm_solve / basinhopping are SciPy itself on an analytic objective: what is rehearsed is the
+    dealing of starts (and of their generators) to the ranks and the gather, not the minimiser."""
+    n_param = 2
+
+    @staticmethod
+    def f(x):
+        return (x[0] - 0.3) ** 2 + 3.0 * (x[1] - 0.1) ** 2 + 0.1 * np.sin(8 * x[0]) * np.cos(5 * x[1])
+
+    def nm_solve(self, starts, split_time, jsfs_row, tol=1e-4, maxiter=1000):
+        from scipy import optimize
+        rs = [optimize.minimize(self.f, s, method="Nelder-Mead", options=dict(xatol=tol, fatol=tol, maxiter=maxiter)) for s in starts]
+        return dict(x=np.array([r.x for r in rs]).reshape(len(rs), 2), llh=np.array([-r.fun for r in rs]), nit=np.array([r.nit for r in rs], dtype=np.int32),
+                    nfev=np.array([r.nfev for r in rs], dtype=np.int32), status=np.array([r.status for r in rs], dtype=np.int32), iterations_issued=7)
+
+    def basinhopping(self, starts, split_time, jsfs_row, rngs, niter=3, **kw):
+        from scipy import optimize
+        rs = [optimize.basinhopping(self.f, s, niter=niter, T=0.5, stepsize=0.05, minimizer_kwargs=dict(method="Nelder-Mead"), rng=np.random.default_rng(g))
+              for s, g in zip(starts, rngs)]
+        return dict(x=np.array([r.x for r in rs]).reshape(len(rs), 2), llh=np.array([-r.fun for r in rs]), nfev=np.array([r.nfev for r in rs], dtype=np.int32),
+                    failures=np.array([r.minimization_failures for r in rs], dtype=np.int32), accepted=np.zeros(len(rs), dtype=np.int32))
+
+
+def _search_inputs():
+    rng = np.random.default_rng(3)
+    return rng.uniform(0.0, 1.0, (7, 2)), [900 + s for s in range(7)]
+
+
+def _worker_search(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from misti_amd.dist import best_per_replicate, bootstrap_sharded
+    from misti_amd.optimize import basinhopping_dev, solve_batched_dev
+    starts, seeds = _search_inputs()
+    eng = StubSearchEngine()
+    x, llh, r = solve_batched_dev(eng, 20.0, starts, np.ones(8), tol=1e-6)
+    bh = basinhopping_dev(eng, 20.0, starts, np.ones(8), seeds, niter=3)
+    split, params, jsfs = tiny_grid()[4:]
+    rows = np.vstack([jsfs, jsfs * 0.5, jsfs * 2.0, jsfs[:1] * 0.25])           # 7 replicates over the ranks
+    table = fake_eval(split, params, rows)
+    best = bootstrap_sharded(lambda a, b: best_per_replicate(table[:, a:b]), rows.shape[0])
+    q.put((rank, x, llh, {k: r[k] for k in ("nit", "nfev", "status")}, bh, best))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_searches_and_bootstrap_scan_sharded_over_ranks(world):
+    """optimize.solve_batched_dev / basinhopping_dev / the bootstrap scan inside a process group: starts (with their generators) and
+    replicates are dealt to the ranks in contiguous blocks, one all_gather each; every rank ends with the unsharded result."""
+    from misti_amd.dist import best_per_replicate
+    starts, seeds = _search_inputs()
+    eng = StubSearchEngine()
+    want = eng.nm_solve(starts, 20.0, None, tol=1e-6)
+    want_bh = eng.basinhopping(starts, 20.0, None, seeds, niter=3)
+    split, params, jsfs = tiny_grid()[4:]
+    rows = np.vstack([jsfs, jsfs * 0.5, jsfs * 2.0, jsfs[:1] * 0.25])
+    want_best = best_per_replicate(fake_eval(split, params, rows))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_search, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, x, llh, counters, bh, best in res:
+        assert np.array_equal(x, want["x"]) and np.array_equal(llh, want["llh"]), rank
+        for k in ("nit", "nfev", "status"):
+            assert np.array_equal(counters[k], want[k]) and counters[k].dtype == np.int32, (rank, k)
+        for k in ("x", "llh", "nfev", "failures"):
+            assert np.array_equal(bh[k], want_bh[k]), (rank, k)
+        assert np.array_equal(best, want_best), rank
+
+
+def test_block_bounds_partition():
+    from misti_amd.dist import block_bounds
+    for n in (0, 1, 7, 1000, 16384):
+        for w in (1, 2, 3, 8):
+            lo = block_bounds(n, w)
+            assert lo[0] == 0 and lo[-1] == n and all(0 <= lo[r + 1] - lo[r] <= -(-n // w) for r in range(w))

@@ -100,8 +100,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.misti_abi_version() == 3 == _lib.ABI_VERSION
-    assert "#define MISTI_ABI_VERSION 3" in hdr
+    assert lib.misti_abi_version() == 4 == _lib.ABI_VERSION
+    assert "#define MISTI_ABI_VERSION 4" in hdr
 
 
 def test_tables_match_oracle_structure():
@@ -154,13 +154,13 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="anchor_a2"):
     import subprocess
-    exe = str(tmp_path / "anchor_a2")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(_lib.lib_path())
     _lib.load()                                              # builds the library if it is missing
     cmd = ["gcc", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "anchor_a2.c"), "-L", libdir, "-lmisti_hip", "-Wl,-rpath," + libdir, "-o", exe]
+           os.path.join(ROOT, "examples", name + ".c"), "-L", libdir, "-lmisti_hip", "-Wl,-rpath," + libdir, "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
 
@@ -173,6 +173,10 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
     if _lib.load().misti_device_count() > 0:
         pytest.skip("a GPU is present: the run itself is tests/test_gpu_golden.py::test_c_example")
     r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+    # ... and the multi-device form (misti_create_multi / misti_multi_eval_batch): same header, same behaviour without a device
+    exe = _build_c_example(tmp_path, "multi_device")
+    r = subprocess.run([exe, "0", "0"], capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stderr
 
 

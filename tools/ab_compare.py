@@ -2,7 +2,7 @@
 """Bitwise A/B of two builds of the library (run on the GPU box).
 
     python -m misti_amd.build --out /tmp/variant.so -DSOMETHING        # a variant build
-    MISTI_LIB=/tmp/variant.so python tools/ab_compare.py dump a.npz    # 300 random models + configs 2 and 3: llk, status, rates, spectra
+    MISTI_LIB_AB=1 MISTI_LIB=/tmp/variant.so python tools/ab_compare.py dump a.npz    # 300 random models + configs 2 and 3: llk, status, rates, spectra
     python tools/ab_compare.py dump b.npz                              # the in-tree build
     python tools/ab_compare.py cmp a.npz b.npz                         # arrays that differ in any bit
 

@@ -3,7 +3,7 @@
 
     python tools/stamp_run.py                                                   # counters: batches, dense evaluations, series terms, speculative steps, ...
     python -m misti_amd.build --out /tmp/stamp.so -DMISTI_STAMP
-    MISTI_LIB=/tmp/stamp.so python tools/stamp_run.py                            # cycle stamps per phase (profiles/rNN_stamp_longest_chain.txt)
+    MISTI_LIB_AB=1 MISTI_LIB=/tmp/stamp.so python tools/stamp_run.py                            # cycle stamps per phase (profiles/rNN_stamp_longest_chain.txt)
 
 The kernel writes its per-chain counters (or, in the stamped build, clock64() differences per phase) into the last row of
 the `pr` output."""
