@@ -391,10 +391,17 @@ def sweep_cases():
 # the candidates of the random campaign (tools/random_campaign.py, seed 1, 600 models) on which the HIP path stands
 # worst against the ORACLE: every one outside the contract there, and the two largest factors inside it
 CAMPAIGN_PICKS = ((1, 148, 12), (1, 515, 0), (1, 515, 2), (1, 515, 4), (1, 515, 6), (1, 583, 3), (1, 547, 2), (1, 202, 0), (1, 353, 0), (1, 198, 1),
-                  (2, 35, 1), (2, 35, 9), (2, 35, 11), (2, 35, 21))       # (campaign seed, model, candidate)
+                  (2, 35, 1), (2, 35, 9), (2, 35, 11), (2, 35, 21),       # (campaign seed, model, candidate)
+                  # round 4: EVERY candidate the first pass of the uniform protocol (tools/uniform_spread.py: 16 + 16 runs of the compiled baseline
+                  # for every candidate of the noise class, fixed before the device was consulted; profiles/r04_random_campaign_seed*.txt) left
+                  # outside the contract - seed 5 is the new held-out fixture
+                  (5, 282, 14), (5, 38, 7), (5, 38, 6), (5, 38, 5), (5, 545, 5), (5, 461, 0),
+                  (1, 446, 1), (1, 446, 2), (1, 446, 3), (1, 446, 4), (1, 446, 5),
+                  (2, 35, 0), (2, 35, 2), (2, 35, 8), (2, 35, 12), (2, 35, 14), (2, 35, 16),
+                  (3, 234, 1), (4, 581, 14), (4, 307, 8))
 
 
-def campaign_cases(kinds=32):
+def campaign_cases(kinds=64):
     """Those candidates run through the REFERENCE itself, with a denser perturbation study (`kinds` perturbed runs each)
     and solver traces: what the campaign measures against the oracle, measured against the reference."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))

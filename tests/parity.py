@@ -100,6 +100,18 @@ KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6}
 # and the gain ratio of a saturated residual is decided below that.  Open.
 
 
+# Default fit at numT = 128 (BASELINE config 3 under the reference's default fit, 16 384 candidates): four candidates on which the reference
+# reports "Lambda correction failed" in all of its 33 runs (base + 16 input perturbations + 16 one-ulp-in-expm) while the HIP path returns a
+# value.  Mechanism, traced on candidate 6761 (tools/trace_candidate.py 6761 config3:default --all; interval 12): the default fit's residual
+# (conditional expected coalescence time, CorrectLambda.py:94-110) has a POLE in the first rate near 0 with a root on either side
+# (+3.7e-4 and -6.2e-4 there); the first Gauss-Newton step from the PSMC rate jumps across the pole, and whether the landing point is
+# accepted (cost 1.5e-8 against 3.0e-8) or rejected (3.3e-8) depends on the step's length to 0.3 %: the reference's forward-difference
+# Jacobian - rounding noise of its inverse-based formula, frozen under 2^-48 input perturbations - makes the step 1.4 % longer than the
+# exact Jacobian does, lands accepted, and follows the negative branch to a root with a negative rate: failure.  The HIP path's Jacobian
+# (the integral series, accurate to ~1e-7) lands 0.3 % short, is rejected, and ends in the positive root.  Documented, not imitated.
+KNOWN_STATUS = {"config3_default_c2398", "config3_default_c6761", "config3_default_c7005", "config3_default_c7734"}
+
+
 def determined(out):
     return out.get("sens") is not None and out["sens"] < SENS_DETERMINED
 
@@ -193,3 +205,15 @@ def baseline_contract(w, idx, hip_llk, hip_status, hip_jafs=None, rep=0, threads
     rel = np.where(both, err / np.maximum(np.abs(c_llk[:, 0]), 1e-300), 0.0)
     return dict(n=len(idx), both=int(both.sum()), tight=int(tight.sum()), self_bound=int(selfb.sum()), outside=np.where(outside)[0], mismatch=np.where(mismatch)[0],
                 rel=rel, run=c_run, worst_tight=float(rel[tight].max()) if tight.any() else 0.0, base_llk=c_llk[:, 0], base_status=c_st, base_jafs=c_jafs)
+
+
+# ---- measured guards -------------------------------------------------------------------------------------------------------------
+def record(name, **numbers):
+    """With MISTI_MEASURE_GUARDS=<file> set, a test appends the counts its guards are pinned to (one JSON line per test): one
+    `pytest -m gpu` run on the GPU box then yields every measured number behind the guards (profiles/rNN_measured_guards.jsonl)."""
+    import json
+    import os
+    path = os.environ.get("MISTI_MEASURE_GUARDS")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=name, **numbers)) + "\n")

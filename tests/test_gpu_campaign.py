@@ -1,8 +1,17 @@
-"""Randomised differential campaign as a test: 4 x 600 random models (seed 4 held out until the code was frozen) (numT 8-40, all flag combinations, bands in both
-directions, pulses, ancient sample, fractional splits), each evaluated as ONE batch of 6-28 candidates through the C
-ABI - so chains are shared and the trunk paths run - against the oracle's value of every candidate
-(tests/golden/campaign_seed{1,2,3}.json.gz, written by `tools/random_campaign.py --make-ref`; 27 minutes of oracle time
-each, plus tools/self_perturbation.py's studies of the oracle's own spread)."""
+"""Randomised differential campaign as a test: 5 x 600 random models (numT 8-40, all flag combinations, bands in both directions, pulses,
+ancient sample, fractional splits), each evaluated as ONE batch of 6-28 candidates through the C ABI - so chains are shared and the trunk
+paths run - against the oracle's value of every candidate (tests/golden/campaign_seed{1..5}.json.gz: tools/random_campaign.py --make-ref).
+
+Round 4's protocol, fixed before the device was consulted (tools/uniform_spread.py): EVERY candidate of the noise class - corrected rate x
+interval length >= 5, default fit with a band or pulse, or "correction failed" in the oracle - has exactly 16 runs on inputs perturbed by
+2^-48 and 16 runs with one ulp of noise in the pair chain's expm (compiled baseline); `spread` = the largest relative change of the llh.
+Nothing is deepened afterwards.  Seed 5 was generated in round 4 and is the held-out fixture.  FIRST-PASS result (profiles/
+r04_random_campaign_seed*.txt): 20 of 35 850 comparable candidates outside (6 of them in seed 5), no status mismatch.  Each of the 20 was
+then run through /root/reference ITSELF with 64 input perturbations, 16 one-ulp-in-expm and 16 one-ulp-in-residual runs
+(tests/golden/golden_campaign.json, tests/test_gpu_golden.py::test_campaign_worst): all 20 lie within the reference's own spread (the
+reference reaches the device's value in its perturbed runs) - 9 of them are default-fit candidates WITHOUT migration, 1.0e-9 ... 2.3e-9 off,
+which the class definition above leaves out and the reference itself moves by 1.1e-9 ... 3.8e-9."""
+import json
 import os
 import sys
 
@@ -10,22 +19,27 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT
+from parity import record
 
 pytestmark = pytest.mark.gpu
 
 
-# Measured on MI355X with this round's build (profiles/r03_random_campaign_seed{1,2,3}.txt): candidates within 1e-9 and the
-# candidates OUTSIDE the contract, pinned by index with their measured distance as the bound.
-MEASURED = {1: dict(n=7648, comparable=7103, tight=5249, outside={1941: 1e-6}),       # model 148 candidate 12 (--cpfit runaway, golden camp_m148_c12: 2.5e-7)
-            2: dict(n=7694, comparable=7080, tight=5379, outside={}),
-            3: dict(n=7434, comparable=6811, tight=5145, outside={}),
-            # held out: generated in round 3 after the solver code was frozen (first pass with 4 perturbations per noise-class candidate:
-            # 13 outside, 9 status mismatches - three chains and one; the reference's 16-perturbation and one-ulp studies of those 22,
-            # profiles/r03_random_campaign_seed4_heldout.txt, then show it moving as far itself)
-            4: dict(n=7579, comparable=6779, tight=5097, outside={})}
+# First pass, measured on MI355X with this round's build: candidates, comparable ones, within 1e-9, and the candidates OUTSIDE the
+# contract under the fixture's uniform spreads (candidate index -> measured relative distance), each of which is a reference-run golden.
+MEASURED = {1: dict(n=7648, comparable=7103, tight=5249, outside={5600: 1.75e-9, 5601: 1.88e-9, 5602: 2.04e-9, 5603: 2.30e-9, 5604: 1.23e-9}),
+            2: dict(n=7694, comparable=7080, tight=5379, outside={464: 1.85e-8, 466: 1.94e-8, 472: 2.38e-8, 476: 2.70e-8, 478: 2.64e-8, 480: 2.56e-8}),
+            3: dict(n=7434, comparable=6811, tight=5145, outside={3137: 1.62e-9}),
+            4: dict(n=7579, comparable=6779, tight=5097, outside={7331: 9.38e-8, 3867: 1.03e-9}),
+            5: dict(n=7561, comparable=6964, tight=5406, outside={3642: 1.87e-6, 559: 6.45e-8, 560: 6.54e-8, 561: 6.96e-8, 6935: 1.13e-9, 5877: 1.01e-9})}
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def studied():
+    """(seed, model, candidate) of every campaign candidate that /root/reference itself was run on."""
+    d = json.load(open(os.path.join(GOLDEN, "golden_campaign.json")))
+    return {(c["campaign"]["seed"], c["campaign"]["model"], c["campaign"]["cand"]) for c in d["cases"]}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_random_batches_against_the_oracle(seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import random_campaign as rc
@@ -36,17 +50,16 @@ def test_random_batches_against_the_oracle(seed):
     ref = rc.load_ref(os.path.join(GOLDEN, "campaign_seed%d.json.gz" % seed), 600, seed, n_jobs)
     rep = rc.compare(cases, ref)
     s = rep["stats"]
+    record("campaign_seed%d" % seed, **{k: int(v) for k, v in s.items()}, outside_list=[(int(b[2]), float(b[0])) for b in rep["outside"]])
     assert s["candidates"] == n_jobs == want["n"]
-    # failure against value only where the reference itself flips under a 2^-48 perturbation: none measured, none allowed
+    # a failure against a value only where the reference (its restatement) itself flips in its 32 runs: none measured, none allowed
     assert s["status_mismatch"] == 0, rep["bad"][:5]
     comparable = s["tight"] + s["self_bound"] + s["internal_bound"] + s["outside"]
     assert comparable >= want["comparable"] - 5           # the rest fails on both sides (negative rates, failed corrections) or is a reference flip
-    # the contract per candidate (tests/parity.py): 1e-9 (+ rounding floor), or 10 x the reference's own spread under 4-64
-    # perturbations of 2^-48 for THAT candidate, or under one ulp in its own pair-chain expm
     assert s["tight"] >= want["tight"] - comparable // 100, (s["tight"], want["tight"])
-    # OUTSIDE: the pinned candidates with their measured distance as the bound, plus at most two stop/continue flips that the
-    # reference's 4-64 perturbed runs did not sample (another build's rounding moves which candidates those are) - small ones
-    extra = [b for b in rep["outside"] if b[2] not in want["outside"]]
-    assert len(extra) <= 2, extra
+    # OUTSIDE under the first-pass spreads: only candidates that have been run through the reference itself (the golden test holds each of
+    # them to the reference's own value and spread), each no farther than measured
+    ref_run = studied()
     for rel, spread, idx, ci, k, split, run, cpfit, kinds, internal in rep["outside"]:
-        assert rel <= want["outside"].get(idx, 1e-6), (idx, rel, spread, run)
+        assert (seed, ci, k) in ref_run, "seed %d candidate %d (model %d cand %d): outside the contract (rel %.3g) and never run through the reference" % (seed, idx, ci, k, rel)
+        assert rel <= 1.5 * want["outside"].get(idx, 1e-9), (idx, rel, spread, run)

@@ -5,7 +5,7 @@ spread, measured at test time through the compiled baseline); plus the propertie
 import numpy as np
 import pytest
 
-from parity import baseline_contract, llk_tol
+from parity import baseline_contract, llk_tol, record
 
 pytestmark = pytest.mark.gpu
 RUNAWAY = 5.0
@@ -20,6 +20,10 @@ def evaluate(name):
         again = e.evaluate(w.split_time, w.params, w.jsfs)          # second batch: launch shape from the first one's chain count
     assert np.array_equal(first.llk, again.llk, equal_nan=True) and np.array_equal(first.status, again.status)
     return w, first
+
+
+# regular candidates of each sample beyond 1e-9 against the oracle, measured on MI355X (profiles/r04_measured_guards.jsonl); the guard is measured + 1
+REGULAR_BEYOND_MEASURED = {"config3": 0, "config4": 0, "config5": 0}
 
 
 def against_oracle(w, res, n_sample, unfolded=False, min_regular=8, max_outside=0):
@@ -43,8 +47,10 @@ def against_oracle(w, res, n_sample, unfolded=False, min_regular=8, max_outside=
                 n_reg += 1
                 if err > llk_tol(o_llk[k, r], w.jsfs[r], res.jafs[c], unfolded):
                     n_out += 1                                            # a gtol stop/continue flip (see test_gpu_grid.py)
-                    assert err <= 1e-7 * abs(o_llk[k, r]), (c, r, res.llk[c, r], o_llk[k, r])
-    assert n_reg >= min_regular and n_out <= max(1, n_reg // 50)
+                    assert err <= 1e-8 * abs(o_llk[k, r]), (c, r, res.llk[c, r], o_llk[k, r])
+    name = w.name.split(":")[0]
+    record("against_oracle_" + name, regular=n_reg, regular_beyond_1e9=n_out)
+    assert n_reg >= min_regular and n_out <= REGULAR_BEYOND_MEASURED[name] + 1
     rep = baseline_contract(w, idx, res.llk, res.status)
     assert len(rep["mismatch"]) == 0
     assert len(rep["outside"]) <= max_outside, [(int(idx[k]), float(rep["rel"][k]), float(rep["run"][k])) for k in rep["outside"]]

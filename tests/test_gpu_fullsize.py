@@ -1,71 +1,128 @@
 """The per-candidate contract of tests/parity.py at BASELINE's full sizes, for EVERY candidate: config 2 (the headline
-grid, 4 096 candidates), a 4 096-candidate sample of config 5 (65 536: ancient sample, band x pulse) and of config 3
-(16 384 random two-band parameter vectors).
+grid, 4 096 candidates) under --cpfit AND under the reference's default fit, a 4 096-candidate sample of config 5 (65 536: ancient
+sample, band x pulse) and of config 3 (16 384 random two-band parameter vectors).  The full grids of configs 3 and 5 (and config 3 under
+the default fit) are checked the same way by tools/fullsize_report.py: profiles/r04_fullsize_contract.txt.
 
-The checker is the compiled CPU baseline (oracle/cpu/misti_cpu.cpp - the reference's algorithm, dense expm + inverse and
-SciPy's TRF restated, pinned on the reference's 154 golden cases): fast enough (~100 candidates/s/core) to evaluate the
-whole grid AND, for every candidate the HIP path does not match to 1e-9, that candidate's own spread under eight 2^-48
-perturbations of the inputs, at test time."""
+First pass - the checker is the compiled CPU baseline (oracle/cpu/misti_cpu.cpp - the reference's algorithm, dense expm + inverse and
+SciPy's TRF restated, pinned on the reference's golden cases): fast enough (~100 candidates/s/core) to evaluate the whole grid AND, for
+every candidate the HIP path does not match to 1e-9, that candidate's own spread under SIXTEEN 2^-48 perturbations of the inputs and
+SIXTEEN runs with one ulp of noise in its pair-chain expm (the same depth for all of them, fixed in advance), at test time.
+Second pass - every candidate the first pass leaves outside must be one that /root/reference ITSELF has been run on (64 input
+perturbations + 16 one-ulp-in-expm + 16 one-ulp-in-residual runs: tests/golden/golden_fullsize.json / golden_default_fit.json,
+tests/golden/make_fullsize.py) and must lie within the contract THERE (tests/test_gpu_golden.py checks each of them against the
+reference's own value and spread).  An outlier without a reference-run study fails the test.
+
+Round 4's finding behind the second pass: where device and baseline disagree beyond the baseline's spread, the reference sides with the
+DEVICE about as often as with the baseline (config 3: all 12 studied candidates, e.g. start 6208 - device 4e-12 from the reference,
+baseline 1.3e-9), and where it sides with the baseline its own perturbed runs reach the device's value (config 5: 31 of 31)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
-from parity import baseline_contract
+from conftest import GOLDEN
+from parity import baseline_contract, record
 
 pytestmark = pytest.mark.gpu
 
+# measured on MI355X with this round's build (profiles/r04_fullsize_contract.txt, profiles/r04_measured_guards.jsonl):
+# candidates with a value on both sides, those within 1e-9, first-pass outside
+MEASURED = {"config2": dict(both=4096, tight=3584, outside=0),
+            "config2:default": dict(both=3264, tight=0, outside=10),
+            "config5/16": dict(both=None, tight=None, outside=None),
+            "config3/4": dict(both=None, tight=None, outside=None)}
 
-def full_contract(w, idx, threads=16, kinds=8):
+
+def studied(workload):
+    """Candidates of `workload` that /root/reference itself was run on (name -> case)."""
+    out = {}
+    for f in ("golden_fullsize.json", "golden_default_fit.json"):
+        p = os.path.join(GOLDEN, f)
+        if os.path.exists(p):
+            for c in json.load(open(p))["cases"]:
+                if c["fullsize"]["workload"] == workload:
+                    out[int(c["fullsize"]["cand"])] = c
+    return out
+
+
+def full_contract(w, idx, threads=16, kinds=16, internal=16):
     from misti_amd.engine import Engine
     split = w.split_time[idx]
     par = None if w.params is None else w.params[idx]
     with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
         r = e.evaluate(split, par, w.jsfs[:1])
     sub = type(w)(w.name, w.times, w.lh, w.bands, w.pulses, w.n_param, w.flags, w.sample_date, split, par, w.truth, w.jsfs)
-    return baseline_contract(sub, np.arange(len(idx)), r.llk, r.status, threads=threads, kinds=kinds)
+    rep = baseline_contract(sub, np.arange(len(idx)), r.llk, r.status, threads=threads, kinds=kinds, internal=internal)
+    rep["hip_llk"], rep["hip_status"] = r.llk[:, 0], r.status
+    return rep
 
 
-def check(rep, min_tight_frac, max_outside):
-    """Guards = what was measured on MI355X with this round's build (profiles/r03_fullsize_contract.txt) minus 2 % / plus 2:
-    a regression in the speculation tree, the reduced pair chain or the trunk moves dozens of candidates and fails here."""
-    assert len(rep["mismatch"]) == 0, rep["mismatch"][:10]
-    assert rep["tight"] >= min_tight_frac * rep["both"], rep
-    # OUTSIDE = beyond 10 x the baseline's spread under EIGHT perturbations: whole chains whose runaway --cpfit solve takes another
-    # gain-ratio branch than the reference's (the class of golden camp_m148_c12: 1e-6 where the reference holds 1e-8), plus at most
-    # one gtol flip of a regular candidate within rounding of the 1e-9 bound
-    assert len(rep["outside"]) <= max_outside, (len(rep["outside"]), rep["rel"][rep["outside"]][:10])
-    for k in rep["outside"]:
-        assert rep["rel"][k] <= 2e-9 or (rep["rel"][k] <= 1e-5 and rep["run"][k] >= 5.0), (k, rep["rel"][k], rep["run"][k])
+def check(key, workload, idx, rep):
+    """Guards = the measured counts (-1 % on the tight count); every first-pass outlier and every status mismatch must carry a
+    reference-run study, under which the device's value (or status) is within the contract."""
+    from parity import SELF_FACTOR, llk_tol
+    want = MEASURED[key]
+    record("fullsize_" + key, both=rep["both"], tight=rep["tight"], self_bound=rep["self_bound"],
+           outside=[(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]], mismatch=[int(idx[k]) for k in rep["mismatch"]])
+    if want["tight"] is not None:
+        assert rep["tight"] >= want["tight"] - rep["both"] // 100, (rep["tight"], want)
+    ref = studied(workload)
+    for k in list(rep["outside"]) + list(rep["mismatch"]):
+        cand = int(idx[k])
+        assert cand in ref, "candidate %d of %s: outside the contract against the compiled baseline (rel %.3g) and never run through the reference" % (cand, workload, rep["rel"][k])
+        o = ref[cand]["out"]
+        h, hs = rep["hip_llk"][k], rep["hip_status"][k]
+        if o["llh"] is None or hs != 0:
+            # a failure against a value: only where the reference itself flips under its perturbed runs
+            flips = (o.get("pert_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0 or o.get("internal_fail", 0) > 0)
+            assert (o["llh"] is None) == (hs != 0) or flips, (cand, o["llh"], hs)
+            continue
+        tol = max(1e-9 * abs(o["llh"]), SELF_FACTOR * max(o.get("spread") or 0.0, o.get("internal_spread") or 0.0) * abs(o["llh"]))
+        assert abs(h - o["llh"]) <= tol, (cand, h, o["llh"], abs(h - o["llh"]) / abs(o["llh"]), o.get("spread"), o.get("internal_spread"))
 
 
 def test_headline_grid_every_candidate():
     """BASELINE config 2 at full size: all 4 096 candidates of the 64 x 64 split x rate grid.
-    Measured: 3 584 within 1e-9 (87.5 %; worst 5.3e-10), 512 within 10 x their spread, NONE outside.  (Until the one-way stiff
-    regime got its closed form - pair_cascade - one chain, rate index 35, sat 2e-6 ... 4e-6 off where the reference holds 1e-10.)"""
+    Measured: 3 584 within 1e-9 (87.5 %; worst 5.3e-10), 512 within 10 x their spread, NONE outside."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config2(lambda *a: truth_spectrum(*a))
-    rep = full_contract(w, np.arange(w.n_cand))
-    check(rep, 0.855, 2)
-    assert rep["both"] == 4096 and rep["worst_tight"] <= 2e-9
+    idx = np.arange(w.n_cand)
+    rep = full_contract(w, idx)
+    check("config2", "config2", idx, rep)
+    assert rep["both"] == 4096 and rep["worst_tight"] <= 2e-9 and len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
+
+
+def test_headline_grid_default_fit_every_candidate():
+    """The headline grid under the reference's DEFAULT fit (MiSTI.py:86,213: --cpfit is opt-in; LambdaSystem, CorrectLambda.py:94-110,303)
+    - what `bench.py --fit default` times - every candidate.  The reference's own value is determined to 1e-6 ... 1e-3 only on this
+    grid (the conditional expected coalescence time of a short interval barely depends on the rate: golden_default_fit.json, 16 + 16
+    reference runs per candidate), so no candidate is within 1e-9 of the compiled baseline and all but a handful are within 10 x
+    their spread; the first-pass outliers are reference-studied (the device is 5 - 8 x closer to the reference there than the baseline is)."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a), cpfit=False)
+    idx = np.arange(w.n_cand)
+    rep = full_contract(w, idx)
+    check("config2:default", "config2:default", idx, rep)
+    assert rep["both"] >= MEASURED["config2:default"]["both"] - 40
+    assert len(rep["outside"]) <= MEASURED["config2:default"]["outside"] + 2
 
 
 def test_config5_sample_every_candidate():
-    """BASELINE config 5 (ancient second genome, band x pulse x split): 4 096 of the 65 536 candidates, evenly spaced.
-    Measured: 3 168 of 4 080 within 1e-9 (77.6 %), 909 within 10 x their spread, 3 outside (two chains, 5e-7 ... 1.2e-6: a gradient
-    test 0.4 % from its threshold)."""
+    """BASELINE config 5 (ancient second genome, band x pulse x split): 4 096 of the 65 536 candidates, evenly spaced."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config5(lambda *a: truth_spectrum(*a))
-    rep = full_contract(w, np.arange(0, w.n_cand, 16))
-    check(rep, 0.756, 5)
+    idx = np.arange(0, w.n_cand, 16)
+    check("config5/16", "config5", idx, full_contract(w, idx))
 
 
 def test_config3_sample_every_candidate():
-    """BASELINE config 3 (two optimised bands, random parameter vectors): 4 096 of the 16 384 starts.
-    Measured: 3 705 of 4 078 within 1e-9 (90.9 %), 366 within 10 x their spread, 7 outside (six runaway starts at 4e-7 ... 5e-6,
-    one regular start at 1.3e-9)."""
+    """BASELINE config 3 (two optimised bands, random parameter vectors): 4 096 of the 16 384 starts."""
     from misti_amd import workloads
     from misti_amd.engine import truth_spectrum
     w = workloads.config3(lambda *a: truth_spectrum(*a))
-    rep = full_contract(w, np.arange(0, w.n_cand, 4))
-    check(rep, 0.888, 9)
+    idx = np.arange(0, w.n_cand, 4)
+    check("config3/4", "config3", idx, full_contract(w, idx))

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import JAFS_RTOL, KNOWN_OUTSIDE, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of
+from parity import JAFS_RTOL, KNOWN_OUTSIDE, KNOWN_STATUS, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of
 
 pytestmark = pytest.mark.gpu
 
@@ -14,6 +14,8 @@ SMALL = load_golden("golden_small")
 SYNTH = load_golden("golden_synthetic")
 SWEEP = load_golden("golden_sweep")
 CAMPAIGN = load_golden("golden_campaign")
+FULLSIZE = load_golden("golden_fullsize")
+DEFAULT_FIT = load_golden("golden_default_fit")
 
 
 def run_case(case):
@@ -34,7 +36,8 @@ def check(case):
     if o["llh"] is None:
         if llh != -np.inf:
             # a value where the reference reports a failure: only where the reference itself flips under a 2^-48 perturbation
-            assert o.get("pert_finite", 0) > 0, (llh, o["stdout"])
+            # (or, where that was studied, under one ulp in its own matrix exponential)
+            assert o.get("pert_finite", 0) > 0 or o.get("internal_finite", 0) > 0, (llh, o["stdout"])
             return
         assert o["stdout"][0] in text
         return
@@ -73,9 +76,9 @@ def test_sweep_one_by_one(case):
 
 @pytest.mark.parametrize("case", CAMPAIGN, ids=[c["name"] for c in CAMPAIGN])
 def test_campaign_worst(case):
-    """The candidates of the random campaign on which the HIP path stands worst against the oracle (all outside the
-    contract there, and the largest factors inside it), against the REFERENCE itself with its spread over 32 perturbed
-    runs and its internal spread (one ulp in its expm, 16 runs)."""
+    """The candidates of the random campaign on which the HIP path stands worst against the oracle - round 3's picks and EVERY
+    candidate the first pass of round 4's uniform protocol left outside the contract (20, six of them from the held-out seed 5) -
+    against the REFERENCE itself with its spread over 64 perturbed runs and its internal spread (one ulp in its expm, 16 runs)."""
     if case["name"] in KNOWN_OUTSIDE:
         m, llh, _ = run_case(case)
         rel = abs(llh - case["out"]["llh"]) / abs(case["out"]["llh"])
@@ -85,6 +88,30 @@ def test_campaign_worst(case):
         except AssertionError:
             pytest.xfail("documented outlier: %.3g relative, outside 10 x both measured spreads" % rel)
         return
+    check(case)
+
+
+@pytest.mark.parametrize("case", FULLSIZE, ids=[c["name"] for c in FULLSIZE])
+def test_fullsize_outliers(case):
+    """Candidates of BASELINE's full-size grids (configs 3 and 5, numT = 128) against the REFERENCE itself: the ten round 3 left outside
+    the contract against the compiled baseline and every one the full-grid check of round 4 flagged (tools/fullsize_report.py, 16 + 16
+    runs per candidate), each with the reference's own spread over 64 input perturbations and 16 one-ulp-in-expm runs
+    (tests/golden/make_fullsize.py).  Every one is within the contract by the reference's own measurement."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", DEFAULT_FIT, ids=[c["name"] for c in DEFAULT_FIT])
+def test_default_fit_at_baseline_size(case):
+    """The reference's DEFAULT fit (MiSTI.py:86,213; LambdaSystem, CorrectLambda.py:94-110,303) with migration at numT = 128: 24 + 24
+    candidates of configs 2 and 3, evenly spaced and fixed before any result was looked at, and the candidates the full-grid check
+    flagged, against the REFERENCE with its own spread over 16 input perturbations and 16 one-ulp-in-expm runs.
+    The reference's own llh is determined to 1e-6 ... 6e-3 only on these grids; every value is within its spread (largest factor 1.3 of
+    the 10 allowed).  KNOWN_STATUS: four candidates of config 3 on which the reference reports "Lambda correction failed" in all of
+    its 33 runs and the device returns a value - documented deviations with their reference-run study, see tests/parity.py."""
+    if case["name"] in KNOWN_STATUS:
+        m, llh, _ = run_case(case)
+        assert case["out"]["llh"] is None and np.isfinite(llh) and m.status == 0
+        pytest.xfail("documented deviation: the reference fails in all 33 runs (second root beyond a pole of its residual), the device returns a value")
     check(case)
 
 

@@ -3,11 +3,12 @@ oracle on a sample, and size-independent properties of the model on the whole ba
 import numpy as np
 import pytest
 
-from parity import baseline_contract, llk_tol
+from parity import baseline_contract, llk_tol, record
 
 pytestmark = pytest.mark.gpu
 
 RUNAWAY = 5.0       # oracle's max corrected rate x interval length above which the reference is noise-driven
+REGULAR_BEYOND_MEASURED = 0
 
 
 @pytest.fixture(scope="module")
@@ -42,10 +43,12 @@ def test_grid_sample_against_oracle(cfg2):
             # 1e-9; observed on ~0.1 % of regular candidates.  Everything else meets the 1e-9 contract.
             if err > llk_tol(o_llk[k, 0], w.jsfs[0], res.jafs[c], False):
                 n_out += 1
-                assert err <= 1e-7 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0])
+                assert err <= 1e-8 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0])
             else:
                 np.testing.assert_allclose(res.jafs[c], oracle_batch.last_jafs[k], rtol=1e-9)
-    assert n_reg >= 60 and n_out <= max(1, n_reg // 100)
+    record("test_grid_sample_against_oracle", regular=n_reg, regular_beyond_1e9=n_out)
+    # measured on MI355X (profiles/r04_measured_guards.jsonl): 80 regular candidates in the sample, NONE beyond 1e-9; the guard is measured + 1
+    assert n_reg >= 60 and n_out <= REGULAR_BEYOND_MEASURED + 1
     # runaway-rate candidates: the per-candidate contract (1e-9, or 10 x that candidate's own spread under eight 2^-48
     # perturbations, measured here through the compiled baseline).  Measured on MI355X: 85 tight, 11 within their spread, none outside
     rep = baseline_contract(w, idx, res.llk, res.status)

@@ -243,3 +243,37 @@ def test_evaluation_budget_is_cut_per_evaluation_as_scipy_does(cfg3):
             assert got["nfev"][s] <= (niter + 1) * maxfev
             cut_seen += got["failures"][s] > 0
     assert cut_seen >= 20                                   # the budget really ran out
+
+
+def test_basinhopping_at_config3_size():
+    """BASELINE config 3 as worded - basin hopping from 16 384 random starts - in one call (2 hops per start here; bench.py
+    --workload config3-basinhopping runs SciPy's default of 100, /root/reference/MigrationInference.py:723-725); 8 sampled starts
+    bit-equal to scipy.optimize.basinhopping on the GPU objective, each with the generator the device was given for that start."""
+    from scipy import optimize
+    import warnings
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    w = workloads.config3(lambda *a: truth_spectrum(*a))
+    assert w.n_cand == 16384
+    split = float(w.split_time[0])
+    niter = 2
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as eng:
+        got = eng.basinhopping(w.params, split, w.jsfs[0], rngs=list(5000 + np.arange(w.n_cand)), niter=niter, T=0.5, stepsize=0.5)
+        assert np.isfinite(got["llh"]).mean() > 0.99
+        assert (got["nfev"] <= (niter + 1) * 400).all()          # three minimisations, each within SciPy's default budget of 200 x N
+        assert (got["failures"] <= niter + 1).all() and got["accepted"].max() <= niter
+
+        def obj(mu):
+            if (np.asarray(mu) < 0).any():
+                return np.inf
+            v = float(eng.evaluate([split], [list(mu)], w.jsfs).llk[0, 0])
+            return -v if np.isfinite(v) else np.inf
+        rng = np.random.default_rng(17)
+        sample = list(rng.choice(w.n_cand, 7, replace=False)) + [int(np.argmax(got["nfev"]))]      # ... and the start that spent the most evaluations
+        for s in sample:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref = optimize.basinhopping(obj, w.params[s], niter=niter, T=0.5, stepsize=0.5, minimizer_kwargs=dict(method="Nelder-Mead"),
+                                            rng=np.random.default_rng(5000 + int(s)))
+            assert np.array_equal(ref.x, got["x"][s]), (s, ref.x, got["x"][s])
+            assert -ref.fun == got["llh"][s] and ref.nfev == got["nfev"][s] and ref.minimization_failures == got["failures"][s], (s, ref.nfev, got["nfev"][s])

@@ -13,6 +13,9 @@ SMALL = load_golden("golden_small")
 SYNTH = load_golden("golden_synthetic")
 SWEEP = load_golden("golden_sweep")
 CAMPAIGN = load_golden("golden_campaign")
+# numT = 128 cases run through the reference in round 4 (tests/golden/make_fullsize.py); ~2 s of oracle each: every fourth / eighth one here
+FULLSIZE = load_golden("golden_fullsize")[::4]
+DEFAULT_FIT = load_golden("golden_default_fit")[::8]
 # the oracle restates the reference operation by operation on the same SciPy, so
 # agreement is at rounding level; 1e-12 leaves room for a different BLAS build
 RTOL = 1e-12
@@ -64,6 +67,18 @@ def test_sweep(case):
 def test_campaign_worst(case):
     """The random campaign's worst candidates (tools/random_campaign.py), run through the reference: the oracle the
     campaign is judged against reproduces the reference on them."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", FULLSIZE, ids=[c["name"] for c in FULLSIZE])
+def test_fullsize_outliers(case):
+    """Full-size candidates (configs 3 and 5) run through the reference: the oracle reproduces the reference there too."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", DEFAULT_FIT, ids=[c["name"] for c in DEFAULT_FIT])
+def test_default_fit_at_baseline_size(case):
+    """The default fit with migration at numT = 128 through the reference: the oracle reproduces it (values AND failures)."""
     check(case)
 
 

@@ -9,7 +9,7 @@
 # one stream so that a launch's counters belong to that launch alone.  Under rocprofv3 the
 # program itself follows `--` (python3 bench.py ...): no env / bash -c hop.
 set -e -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}          # all | bench | trace | pmc
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -26,6 +26,8 @@ for wl in config3 config4 config5; do
   echo "bench $wl done"
 done
 python3 bench.py --workload config2x16 --steps 32 --warmup 4 --no-cpu-baseline > "$OUT/bench_config2x16.json" 2>> "$OUT/bench.err"
+python3 bench.py --steps 20 --warmup 20 > "$OUT/bench_driver_steps20.json" 2>> "$OUT/bench.err"      # the driver's own invocation shape (one 20-step region per repeat)
+python3 bench.py --fit default --no-cpu-baseline --no-extra-legs > "$OUT/bench_default_fit.json" 2>> "$OUT/bench.err"
 python3 bench.py --workload config3-search --steps 2 --warmup 1 > "$OUT/bench_config3_search.json" 2>> "$OUT/bench.err"
 if python3 bench.py --workload config3-basinhopping --steps 1 --warmup 1 > "$OUT/bench_config3_basinhopping.json" 2>> "$OUT/bench.err"; then echo "basinhopping done"; else echo "basinhopping leg failed (see bench.err)"; fi
 # the RCCL path with one rank (rehearsal of --gpus N): weak (headline) and strong (ONE grid sharded; configs 4 and 5)
@@ -51,6 +53,9 @@ for wl in $WORKLOADS; do
       --output-format csv -d "$OUT/pmc_sq_$wl" -- python3 bench.py --workload $wl $SHORT > /dev/null 2>> "$OUT/bench.err"
   rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY \
       --output-format csv -d "$OUT/pmc_sq2_$wl" -- python3 bench.py --workload $wl $SHORT > /dev/null 2>> "$OUT/bench.err" || echo "second SQ pass failed for $wl"
+  # fp64 arithmetic priced as fp64: wave-instructions by class - an FMA is two flops per lane, the rest one
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT \
+      --output-format csv -d "$OUT/pmc_f64_$wl" -- python3 bench.py --workload $wl $SHORT > /dev/null 2>> "$OUT/bench.err" || echo "fp64 class pass failed for $wl"
   echo "pmc $wl done"
 done
 fi

@@ -104,6 +104,8 @@ def main():
         return
     ref = load_ref(a.ref, a.models, a.seed, len(jobs))
     report = compare(cases, ref, dump=a.dump)
+    import gzip
+    report["protocol"] = json.load(gzip.open(a.ref, "rt")).get("protocol") if a.ref.endswith(".gz") else None
     print("models %d  seed %d" % (a.models, a.seed))
     print_report(report)
 
@@ -185,8 +187,9 @@ def compare(cases, ref, dump=""):
 
 def print_report(rep):
     stats = rep["stats"]
-    print("# reference values and spreads of this report: the NumPy/SciPy ORACLE (oracle/misti_oracle.py: the reference's own SciPy calls; agrees with the")
-    print("# reference to <= 1e-12, bit for bit on almost every case, on the 168 reference-generated goldens), not /root/reference itself")
+    print("# reference VALUES of this report: the NumPy/SciPy ORACLE (oracle/misti_oracle.py: the reference's own SciPy calls; agrees with the reference to")
+    print("# <= 1e-12, bit for bit on almost every case, on the reference-generated goldens), not /root/reference itself.  SPREADS: the fixture's protocol -")
+    print("# " + (rep.get("protocol") or "round 3: the oracle under 4-64 input perturbations, deepened for single candidates"))
     print(stats)
     print("within 1e-9 (+ rounding floor): %d, worst %.3g" % (stats["tight"], rep["worst_tight"]))
     print("within 10 x the reference's own measured spread under input perturbations: %d, worst factor %.2f" % (stats["self_bound"], rep["worst_factor"]))

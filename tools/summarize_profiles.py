@@ -70,17 +70,20 @@ KERNEL1 = {"config2": ("misti::correct_follow_kernel",), "config2x16": ("misti::
            "config3": ("misti::correct_kernel<true, 6>", "misti::correct_resume_kernel"),
            "config5": ("misti::correct_kernel<true, 6>", "misti::correct_resume_kernel")}
 SQ = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
-      "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY")
+      "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+      "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64",
+      "SQ_INSTS_VALU_CVT")
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     for a, b in (("bench.json", "_bench.json"), ("bench_serial.json", "_bench_serial.json"), ("bench_config3.json", "_bench_config3.json"),
                  ("bench_config4.json", "_bench_config4.json"), ("bench_config5.json", "_bench_config5.json"), ("bench_config2x16.json", "_bench_config2x16.json"),
                  ("bench_config3_search.json", "_bench_config3_search.json"), ("bench_config3_basinhopping.json", "_bench_config3_basinhopping.json"),
+                 ("bench_driver_steps20.json", "_bench_driver_steps20.json"), ("bench_default_fit.json", "_bench_default_fit.json"),
                  ("bench_dist_weak.json", "_bench_dist_weak_1rank.json"),
                  ("bench_dist_strong_config4.json", "_bench_dist_strong_config4_1rank.json"),
                  ("bench_dist_strong_config5.json", "_bench_dist_strong_config5_1rank.json")):
@@ -98,7 +101,7 @@ def main():
               "workloads": {}}
     for wl in WORKLOADS:
         counters = {}
-        for sub in ("pmc_fetch_", "pmc_write_", "pmc_sq_", "pmc_sq2_"):
+        for sub in ("pmc_fetch_", "pmc_write_", "pmc_sq_", "pmc_sq2_", "pmc_f64_"):
             for k, d in pmc_last(os.path.join(src, sub + wl)).items():
                 counters.setdefault(k, {}).update(d)
         if not counters:
