@@ -295,6 +295,9 @@ def dry_run(a, json_fd):
 FIT_OVERRIDE = [""]
 
 
+EXTRA_LEGS_TIMEOUT_S = 300     # multi-rank runs: wall-clock bound on the secondary legs together (see main())
+
+
 def build_workload(name, spec):
     from misti_amd import workloads
     w = workloads.BUILDERS[name](spec)
@@ -594,7 +597,22 @@ def main():
     out_spectra_per_s = job_cands * a.steps / dt
 
     # ---- secondary legs (every rank runs them: they contain collectives) -------------------------------------------------
+    # A secondary leg must never cost the headline line.  With several ranks a leg that raises on ONE rank only (an out-of-memory on one
+    # GPU, a HIP error) leaves the others inside a collective for ever: a watchdog on every rank bounds the legs - when it
+    # expires rank 0 emits the headline line as it stands (the legs marked as timed out) and every rank leaves, exit status 0.
     extra = {}
+    watchdog = None
+    if not a.no_extra_legs and world > 1:
+        import threading
+        headline_only = dict(out, extra_legs={"error": "a secondary leg did not finish within %d s on every rank; headline leg only" % EXTRA_LEGS_TIMEOUT_S})
+
+        def expire():
+            if rank == 0:
+                os.write(json_fd, (json.dumps(headline_only) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(EXTRA_LEGS_TIMEOUT_S, expire)
+        watchdog.daemon = True
+        watchdog.start()
     if not a.no_extra_legs:
         short = max(8, min(a.steps, 64))
         if world > 1:
@@ -620,6 +638,9 @@ def main():
             except Exception as e:                 # noqa: BLE001
                 extra["host_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+    if watchdog is not None:
+        fence()                                    # every rank is through its secondary legs
+        watchdog.cancel()
     if rank == 0:
         out.update(extra)
         out["single_batch"] = {"value": job_cands * R * k_serial / dt_serial, "ms_per_step": 1e3 * dt_serial / k_serial, "steps": k_serial,

@@ -215,5 +215,6 @@ def record(name, **numbers):
     import os
     path = os.environ.get("MISTI_MEASURE_GUARDS")
     if path:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, "a") as f:
             f.write(json.dumps(dict(test=name, **numbers)) + "\n")

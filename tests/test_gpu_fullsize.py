@@ -30,8 +30,8 @@ pytestmark = pytest.mark.gpu
 # candidates with a value on both sides, those within 1e-9, first-pass outside
 MEASURED = {"config2": dict(both=4096, tight=3584, outside=0),
             "config2:default": dict(both=3264, tight=0, outside=10),
-            "config5/16": dict(both=None, tight=None, outside=None),
-            "config3/4": dict(both=None, tight=None, outside=None)}
+            "config5/16": dict(both=4080, tight=3168, outside=0),
+            "config3/4": dict(both=4078, tight=3705, outside=1)}        # start 9412: the device 2.3e-9 from the REFERENCE, the baseline 5.2e-6
 
 
 def studied(workload):

@@ -43,7 +43,7 @@ def random_case(rng):
 # Measured on MI355X with this round's build (profiles/r04_measured_guards.jsonl): of the 120 models, those within 1e-9, those within 10 x
 # the oracle's own spread (eight 2^-48 input perturbations + eight one-ulp-in-expm runs, the same depth for every model that is not within
 # 1e-9), and those outside - pinned by their position in the sequence with the measured distance as the bound.
-MEASURED = dict(checked=120, tight=None, self_bound=None, outside={})
+MEASURED = dict(checked=120, tight=102, self_bound=11, outside={})
 
 
 def oracle_spread(c, o_llk, kinds=8, runs=8):

@@ -26,7 +26,7 @@ def test_iteration_history(name):
     r = compare_case(case, ref)
     fd = r["first_diff"]
     assert r["max_rel_before"] <= 1e-5, r                        # trial points of the solves before the first differing one
-    if name.startswith("camp_s2_m35"):
+    if name in ("camp_s2_m35_c1", "camp_s2_m35_c9", "camp_s2_m35_c11", "camp_s2_m35_c21"):
         # round 2's documented outlier: the migrating interval of the default fit took the reference three evaluations and the
         # device two (its noise-free residual satisfied gtol one evaluation early).  Now the same iteration, solve by solve -
         # and the solver word says why (bit 24: went on past a gradient test only the reference's noisy residual fails)
