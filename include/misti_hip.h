@@ -151,8 +151,9 @@ int misti_sync(misti_ctx* ctx);
  *                                  only by a fractional split; unused rows = 0
  *   pr         [n_cand][numT+2][6] or NULL   pair-state trace (.Pr, :309,:350):
  *                                  row t = p11 g1,g2, p22 g1,g2, p12 g1,g2; the last row (numT+1)
- *                                  carries work counters of the correction: residual batches,
- *                                  dense (stiff) exponentials, series terms, squarings, max nfev
+ *                                  carries work counters of the correction: [0] residual batches, [3] solver steps taken
+ *                                  from speculative slots, [4] max nfev, [5] regularised (SVD) steps; [1] dense (stiff)
+ *                                  exponentials and [2] series terms only in a -DMISTI_WORK_COUNTERS=1 build (0 otherwise)
  *   status     [n_cand]     or NULL   MISTI_OK / MISTI_NEG_PARAM / ...
  */
 int misti_eval_batch(misti_ctx* ctx, int64_t n_cand,

@@ -192,6 +192,13 @@ struct Model {
 // v <- exp(M) v by uniformisation.  Every lane carries its own (l, v); the trip
 // count is wave-uniform (bound from the largest q in the wave).
 // Per-candidate diagnostics of the correction: overflow guard and work counters.
+// Work counters of a chain (last row of the `pr` output).  evals, max_nfev, lm and spec are wave-uniform (scalar registers) and always
+// counted; dense, terms and squarings are counted INSIDE the per-lane evaluation and cost three vector registers carried through the
+// whole solver loop - exactly what pushed correct_follow_kernel<true> into scratch (10 spilled VGPRs, 44 B; round 4) - so they are
+// counted in the diagnostic build only (-DMISTI_WORK_COUNTERS=1: tools/stamp_run.py) and read 0 otherwise.
+#ifndef MISTI_WORK_COUNTERS
+#define MISTI_WORK_COUNTERS 0
+#endif
 struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings = 0, max_nfev = 0, lm = 0, spec = 0; };
 // K terms of the Taylor series of exp(M) v for the pair generator, fully unrolled.
 // INT: also  vint = sum_k (M^k v / k!) / (k + 2)  =  int_0^1 u exp(u M) v du  - the default fit's expected coalescence
@@ -215,7 +222,9 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
         a0 += p0; a1 += p1; a2 += p2;
         if (INT) { const double w2 = 1.0 / (double)(k + 2); b0 = fma(p0, w2, b0); b1 = fma(p1, w2, b1); b2 = fma(p2, w2, b2); }
     }
+#if MISTI_WORK_COUNTERS
     dg.terms += K;
+#endif
     v[0] = a0; v[1] = a1; v[2] = a2;
     if (INT) { vint[0] = b0; vint[1] = b1; vint[2] = b2; }
 }
@@ -302,7 +311,9 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         // vanishes): dense scaling and squaring of the 3x3 matrix, degree-12 Taylor kernel
         int sq = 0;
         { double nrm = 2.0 * nbmax; while (nrm > 0.25) { nrm *= 0.5; ++sq; } }
+#if MISTI_WORK_COUNTERS
         dg.dense += 1; dg.squarings += sq;
+#endif
         double scl = ldexp(1.0, -sq);
         if (mu1 == 0.0 || mu0 == 0.0) {
             // Migration in one direction only: the pair chain is a cascade S -> "one in each" -> K (S = both in the population that
@@ -313,7 +324,9 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
             // scaled-and-squared Taylor kernel used here before (13 squarings at rate x length 700) put it on the wrong side on the
             // headline grid: one chain of 64, 2e-6 ... 4e-6 in the likelihood where the reference holds 1e-10.
             pair_cascade(mu1 == 0.0 ? 1 : 2, l0, l1, mu0, mu1, v);
+#if MISTI_WORK_COUNTERS
             dg.dense += 1;
+#endif
             if (!ok) { v[0] = v[1] = v[2] = NAN; }
             return;
         }
@@ -380,7 +393,9 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
             p0 = t0; p1 = t1; p2 = t2;
             a0 += p0; a1 += p1; a2 += p2;
             b *= nbs * inv;
+#if MISTI_WORK_COUNTERS
             dg.terms += 1;
+#endif
             if (b < 1e-19 && (double)k > nbs) break;
         }
         v[0] = a0; v[1] = a1; v[2] = a2;

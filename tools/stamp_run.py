@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-chain work of the correction kernel on the headline grid (run on the GPU box).
 
-    python tools/stamp_run.py                                                   # counters: batches, dense evaluations, series terms, speculative steps, ...
+    python tools/stamp_run.py                                                   # counters: batches, speculative steps, max nfev, SVD steps (dense evaluations
+                                                                                # and series terms too with a -DMISTI_WORK_COUNTERS=1 build)
     python -m misti_amd.build --out /tmp/stamp.so -DMISTI_STAMP
     MISTI_LIB_AB=1 MISTI_LIB=/tmp/stamp.so python tools/stamp_run.py                            # cycle stamps per phase (profiles/rNN_stamp_longest_chain.txt)
 
