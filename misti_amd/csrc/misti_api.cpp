@@ -377,6 +377,14 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         if (c->tune.follow_max <= 0 && busy_from > 0 && est > misti::FOLLOW_BUSY_CHAINS && est <= follow_max && busy() >= busy_from)
             follow_max = misti::FOLLOW_BUSY_CHAINS;
         cpw = (est >= 0 && est <= follow_max) ? 1 : misti::correct_cands_per_wave(n_cand, c->tune);
+        // The default fit's one-chain-per-wave kernel holds ONE wave per SIMD (512 registers): with its trunk wave beside it a 64-chain batch
+        // takes 128 of the chip's 1 024 wave slots and eight batches fill it, where --cpfit fits sixteen.  With other contexts' batches in
+        // flight a small default-fit batch therefore packs two chains per wave (trunks in the next launch): measured on the headline grid
+        // with 20 batches in flight 2.03 -> 2.62e7 evals/s (4 per wave 2.39, 8: 1.94, 10: 2.11; trunks after the chains but one chain
+        // per wave 2.46); alone it keeps the latency shape (1.73 ms against 2.54).  The result never depends on it.
+        if (!(c->dm.flags & MISTI_CPFIT) && cpw == 1 && est >= 0 && est <= misti::FOLLOW_BUSY_CHAINS && busy_from > 0 && c->tune.follow_max <= 0 &&
+            busy() >= busy_from)
+            cpw = 2;
         const int f = c->tune.chains_per_wave;                       // diagnostic override (scratch experiments, tests)
         if (f == 1 || f == 2 || f == 4 || f == 8 || f == 10) cpw = f;
         follow = misti::trunk_follows(cpw, (int64_t)ntr, c->tune);

@@ -105,3 +105,22 @@ def test_busy_device_changes_the_launch_shape_not_the_results():
     for llk, jafs, status in out:
         assert np.array_equal(status, alone.status)
         assert np.array_equal(llk, alone.llk, equal_nan=True) and np.array_equal(jafs, alone.jafs, equal_nan=True)
+
+
+def test_busy_device_packs_small_default_fit_batches_without_changing_results():
+    """The default fit's one-chain-per-wave kernel holds one wave per SIMD, so a 64-chain default-fit batch packs two chains per wave
+    when three or more other contexts have batches in flight (run_dev, misti_api.cpp: 2.0 -> 2.6e7 evals/s on the headline grid with 20
+    batches in flight) and keeps the latency shape alone: 12 batches overlapped on 6 lanes against the same batch alone, bit for bit."""
+    from misti_amd import workloads
+    from misti_amd.engine import Engine, truth_spectrum
+    from misti_amd.lanes import LanePool
+    w = workloads.config2(lambda *a: truth_spectrum(*a), n_split=16, n_rate=64, first_split=60, cpfit=False)
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        e.evaluate(w.split_time, w.params, w.jsfs)
+        alone = e.evaluate(w.split_time, w.params, w.jsfs)
+    with LanePool(w.times, w.lh, lanes=6, **w.engine_kwargs()) as pool:
+        pool.map([(w.split_time, w.params, w.jsfs)] * 6)                      # every lane learns its chain count
+        out = pool.map([(w.split_time, w.params, w.jsfs)] * 18)
+    for llk, jafs, status in out:
+        assert np.array_equal(status, alone.status)
+        assert np.array_equal(llk, alone.llk, equal_nan=True) and np.array_equal(jafs, alone.jafs, equal_nan=True)
