@@ -36,6 +36,9 @@ from . import io as mio
 from .engine import BatchResult, Engine, MigrationInference
 
 
+RANK_MODULE = "misti_amd.cli"       # what `--gpus N` starts N times (a test driver that wraps this module names itself here)
+
+
 def build_parser():
     p = argparse.ArgumentParser(description="Migration inference from PSMC (MI355X engine).")
     p.add_argument("fpsmc1", help="psmc file 1")
@@ -73,15 +76,9 @@ def build_parser():
 
 def _evaluator(a, inp, bands, pulses, k, device):
     """The batch evaluator of grid mode: ``evaluate(split, params, rows)`` -> an object with ``llk[n][R]`` and ``status[n]``, and a
-    function closing it.  The HIP engine on ``device`` (``--devices``: the multi-device form).  MISTI_TEST_EVALUATOR=module:factory
-    replaces the engine by ``factory(times, lambdas, bands, pulses, n_param, flags, sample_date, mixture_th)``: the hook of the CPU
-    tests, which have no GPU (tests/test_dist_cpu.py runs the rank launch over gloo with the oracle behind it) - never set otherwise."""
+    function closing it: the HIP engine on ``device``, or on the device list of ``--devices`` (the multi-device C ABI).  There is no
+    other evaluator: without a usable GPU the constructor fails."""
     flags = dict(cpfit=a.cpfit, true_eps=a.trueEPS, smooth=not a.nosmooth, unfolded=a.uf)
-    hook = os.environ.get("MISTI_TEST_EVALUATOR", "")
-    if hook:
-        import importlib
-        mod, fn = hook.split(":")
-        return getattr(importlib.import_module(mod), fn)(inp.times, inp.lambdas, bands, pulses, k, flags, inp.sampleDateDiscr, a.mth), lambda: None
     if a.devices:
         from .engine import MultiEngine
         e = MultiEngine(inp.times, inp.lambdas, bands, pulses, n_param=k, sample_date=inp.sampleDateDiscr, mixture_th=a.mth,
@@ -174,7 +171,7 @@ def main(argv=None):
             # HIP and never does (a process that has initialised the GPU must not be forked or replaced); the reference's way of
             # using N processors is `parallel -j N ./MiSTI.py ... >> res.out` (/root/reference/README.md:110-115).
             from . import dist as mdist
-            code, out = mdist.launch_ranks(a.gpus, list(sys.argv[1:] if argv is None else argv), module="misti_amd.cli")
+            code, out = mdist.launch_ranks(a.gpus, list(sys.argv[1:] if argv is None else argv), module=RANK_MODULE)
             sys.stdout.write(out)
             sys.stdout.flush()
             return code

@@ -1,13 +1,17 @@
-"""Test hook of misti_amd.cli (MISTI_TEST_EVALUATOR=cli_oracle_hook:make): the batch evaluator of grid mode with the CPU oracle
-behind it, for the gloo runs of tests/test_dist_cpu.py - there is no GPU in the build container.  TEST INFRASTRUCTURE."""
+"""`python -m cli_oracle_hook <misti_amd.cli arguments>`: the command line of misti_amd.cli with the CPU oracle in place of the HIP engine, for
+the gloo runs of tests/test_dist_cpu.py - there is no GPU in the build container, and what those tests rehearse is the rank launch, the
+dealing of chains and the gather, not the engine.  The product module has no such switch: this driver replaces `cli._evaluator` from the
+outside and names itself as the module `--gpus N` starts.  TEST INFRASTRUCTURE."""
+import sys
 import warnings
 from types import SimpleNamespace
 
 import numpy as np
 
 
-def make(times, lambdas, bands, pulses, n_param, flags, sample_date, mixture_th):
+def oracle_evaluator(a, inp, bands, pulses, k, device):
     from oracle.batch import oracle_eval
+    flags = dict(cpfit=a.cpfit, true_eps=a.trueEPS, smooth=not a.nosmooth, unfolded=a.uf)
 
     def evaluate(split, params, rows):
         rows = np.asarray(rows, dtype=float).reshape(-1, 8)
@@ -17,7 +21,14 @@ def make(times, lambdas, bands, pulses, n_param, flags, sample_date, mixture_th)
             warnings.simplefilter("ignore")
             for i, s in enumerate(split):
                 p = None if params is None else list(params[i])
-                v, _, st, _ = oracle_eval(times, lambdas, bands, pulses, flags, sample_date, float(s), p, rows, mixture_th)
+                v, _, st, _ = oracle_eval(inp.times, inp.lambdas, bands, pulses, flags, inp.sampleDateDiscr, float(s), p, rows, a.mth)
                 llk[i], status[i] = v, st
         return SimpleNamespace(llk=llk, status=status, fraction_failed=float((status != 0).mean()))
-    return evaluate
+    return evaluate, (lambda: None)
+
+
+if __name__ == "__main__":
+    from misti_amd import cli
+    cli._evaluator = oracle_evaluator
+    cli.RANK_MODULE = "cli_oracle_hook"
+    sys.exit(cli.main())

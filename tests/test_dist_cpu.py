@@ -202,14 +202,13 @@ def _cli_fixture(tmp_path):
 def test_cli_gpus_starts_its_own_ranks_and_prints_the_unsharded_sweep(tmp_path):
     """`python -m misti_amd.cli ... --grid-st --grid-mi --all-bs --gpus 2`: the process starts two ranks (torch.distributed.run over
     gloo here, RCCL on a node), whole chains are dealt to them, rank 0 prints - the same lines as the one-process sweep.  The oracle
-    stands in for the engine (MISTI_TEST_EVALUATOR: no GPU here); the parent never imports torch."""
+    stands in for the engine (tests/cli_oracle_hook.py wraps the module from the outside: no GPU here); the parent never imports torch."""
     import subprocess
     args = _cli_fixture(tmp_path)
-    env = dict(os.environ, MISTI_TEST_EVALUATOR="cli_oracle_hook:make", MISTI_DIST_BACKEND="gloo", PYTHONDONTWRITEBYTECODE="1",
-               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
-    one = subprocess.run([sys.executable, "-m", "misti_amd.cli"] + args, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    env = dict(os.environ, MISTI_DIST_BACKEND="gloo", PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    one = subprocess.run([sys.executable, "-m", "cli_oracle_hook"] + args, capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-X", "importtime", "-m", "misti_amd.cli"] + args + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    two = subprocess.run([sys.executable, "-X", "importtime", "-m", "cli_oracle_hook"] + args + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     rows = lambda text: [l for l in text.splitlines() if l.startswith("bs_id =") or l.startswith("best:") or l.startswith("bootstrap:")]
     assert len(rows(one.stdout)) == 4 * 3 * 5 + 2 and rows(two.stdout) == rows(one.stdout)
@@ -218,12 +217,11 @@ def test_cli_gpus_starts_its_own_ranks_and_prints_the_unsharded_sweep(tmp_path):
     assert parent_imports and not any(l.rstrip().endswith(" torch") for l in parent_imports)      # the launching process stays off torch / HIP
 
 
-def test_cli_gpus_without_a_gpu_and_without_the_hook_fails_loudly(tmp_path):
-    """No CPU fallback behind --gpus either: every rank needs its GPU."""
+def test_cli_gpus_without_a_gpu_fails_loudly(tmp_path):
+    """No CPU path behind --gpus either: the product module itself, without a GPU, fails on every rank."""
     import subprocess
     args = _cli_fixture(tmp_path)
     env = dict(os.environ, MISTI_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
-    env.pop("MISTI_TEST_EVALUATOR", None)
     r = subprocess.run([sys.executable, "-m", "misti_amd.cli"] + args + ["--gpus", "2"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
     assert r.returncode != 0 and "bs_id =" not in r.stdout
 
