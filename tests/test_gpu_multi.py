@@ -101,3 +101,20 @@ def test_c_example_multi_device(tmp_path):
     assert int(out["contexts"]) == 2 and int(out["identical"]) == 1 and int(out["status"]) == 0
     assert abs(float(out["llh"]) - (-211.9189044185307)) <= 1e-9 * 212
     assert "6 candidates in 2 chains" in r.stdout
+
+
+def test_multi_device_edge_shapes(grid):
+    """Empty batch, spectrum-only (no replicates), and fewer chains than contexts (contexts without a candidate stay idle)."""
+    from misti_amd.engine import Engine, MultiEngine
+    w = grid
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e, MultiEngine(w.times, w.lh, devices=(0, 0, 0), **w.engine_kwargs()) as m:
+        r = m.evaluate(np.zeros(0), np.zeros((0, 1)), w.jsfs)
+        assert r.llk.shape == (0, 3) and r.status.shape == (0,) and m.last_shards() == ([0, 0, 0], [0, 0, 0])
+        one = e.evaluate(w.split_time[:24], w.params[:24], None)
+        got = m.evaluate(w.split_time[:24], w.params[:24], None)
+        assert got.llk.shape == (24, 0) and np.array_equal(got.jafs, one.jafs, equal_nan=True) and np.array_equal(got.status, one.status)
+        sel = np.arange(0, w.n_cand, 10)                               # one rate = one chain: 12 splits of it
+        one = e.evaluate(w.split_time[sel], w.params[sel], w.jsfs)
+        got = m.evaluate(w.split_time[sel], w.params[sel], w.jsfs)
+        assert m.last_shards() == ([12, 0, 0], [1, 0, 0])
+        assert np.array_equal(got.llk, one.llk, equal_nan=True)
