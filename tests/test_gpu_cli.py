@@ -78,6 +78,15 @@ def test_optimised_band_and_grid(tmp_path):
     assert m, text[-800:]
     mean, lo, hi = (float(v) for v in m.groups())
     assert 18 <= lo <= mean <= hi <= 22
+    # the same sweep on a device LIST from this one process (misti_create_multi; two contexts on the one GPU of the box): the same lines
+    rc2, text2 = run_cli([f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "--grid-st", "18", "22",
+                          "--grid-mi", "0", "0.001", "0.1", "4", "--all-bs", "--funits", str(tmp_path / "x"), "--devices", "0,0"])
+    rows = lambda t: [l for l in t.splitlines() if l.startswith("bs_id =") or l.startswith("best:") or l.startswith("bootstrap:")]
+    assert rc2 == 0 and rows(text2) == rows(text)
+    # ... and with one rank per GPU started by the command itself (--gpus 1 here is the plain path; N > 1 over gloo: tests/test_dist_cpu.py)
+    rc3, text3 = run_cli([f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "--grid-st", "18", "22",
+                          "--grid-mi", "0", "0.001", "0.1", "4", "--all-bs", "--funits", str(tmp_path / "x"), "--gpus", "1"])
+    assert rc3 == 0 and rows(text3) == rows(text)
 
 
 def _tokens_match(ours, theirs, rtol):
