@@ -625,6 +625,27 @@ def main():
                                      else "every rank its own config-2 grid")
             except Exception as e:                 # noqa: BLE001
                 extra[other] = {"error": "%s: %s" % (type(e).__name__, e)}
+            # ... and BASELINE config 3 as a search, strong: ONE Nelder-Mead search of 16 384 starts, the starts dealt to the ranks in
+            # contiguous blocks, one all_gather of the results (misti_amd.optimize.solve_batched_dev inside the process group)
+            try:
+                from misti_amd.optimize import solve_batched_dev
+                w3 = build_workload("config3", spec)
+                with Engine(w3.times, w3.lh, device=local_rank, **w3.engine_kwargs()) as eng3:
+                    search = lambda: solve_batched_dev(eng3, float(w3.split_time[0]), w3.params, w3.jsfs[0], tol=1e-4, maxiter=1000)[2]
+                    search()                       # allocates the search state
+                    fence()
+                    t0 = time.perf_counter()
+                    r3 = search()
+                    fence()
+                    dt3 = time.perf_counter() - t0
+                t3 = torch.tensor([dt3], dtype=torch.float64, device=dev)
+                dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+                dt3 = float(t3.item())
+                extra["strong_search"] = {"workload": "config3-search: Nelder-Mead from %d random starts, starts dealt to the ranks in contiguous blocks, one all_gather" % w3.n_cand,
+                                          "value": float(r3["nfev"].sum()) / dt3, "unit": "objective evaluations/s incl. optimiser", "s_per_search": dt3,
+                                          "starts": int(w3.n_cand), "starts_per_rank": -(-int(w3.n_cand) // world), "converged_fraction": float((r3["status"] == 0).mean())}
+            except Exception as e:                 # noqa: BLE001
+                extra["strong_search"] = {"error": "%s: %s" % (type(e).__name__, e)}
         elif a.workload == "config2":
             # ONE call on ONE stream at the overlapped rate: 16 config-2 grids with distinct rate axes in one batch
             try:
