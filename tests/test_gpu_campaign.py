@@ -1,4 +1,4 @@
-"""Randomised differential campaign as a test: 5 x 600 random models (numT 8-40, all flag combinations, bands in both directions, pulses,
+"""Randomised differential campaign as a test: 6 x 600 random models (numT 8-40, all flag combinations, bands in both directions, pulses,
 ancient sample, fractional splits), each evaluated as ONE batch of 6-28 candidates through the C ABI - so chains are shared and the trunk
 paths run - against the oracle's value of every candidate (tests/golden/campaign_seed{1..5}.json.gz: tools/random_campaign.py --make-ref).
 
@@ -10,7 +10,8 @@ r04_random_campaign_seed*.txt): 20 of 35 850 comparable candidates outside (6 of
 then run through /root/reference ITSELF with 64 input perturbations, 16 one-ulp-in-expm and 16 one-ulp-in-residual runs
 (tests/golden/golden_campaign.json, tests/test_gpu_golden.py::test_campaign_worst): all 20 lie within the reference's own spread (the
 reference reaches the device's value in its perturbed runs) - 9 of them are default-fit candidates WITHOUT migration, 1.0e-9 ... 2.3e-9 off,
-which the class definition above leaves out and the reference itself moves by 1.1e-9 ... 3.8e-9."""
+which the class definition above leaves out and the reference itself moves by 1.1e-9 ... 3.8e-9.  Seed 6 - generated after all that, with
+every default-fit candidate in the class - has NO candidate outside in its first pass (6 805 comparable) and no status mismatch."""
 import json
 import os
 import sys
@@ -30,7 +31,10 @@ MEASURED = {1: dict(n=7648, comparable=7103, tight=5249, outside={5600: 1.75e-9,
             2: dict(n=7694, comparable=7080, tight=5379, outside={464: 1.85e-8, 466: 1.94e-8, 472: 2.38e-8, 476: 2.70e-8, 478: 2.64e-8, 480: 2.56e-8}),
             3: dict(n=7434, comparable=6811, tight=5145, outside={3137: 1.62e-9}),
             4: dict(n=7579, comparable=6779, tight=5097, outside={7331: 9.38e-8, 3867: 1.03e-9}),
-            5: dict(n=7561, comparable=6964, tight=5406, outside={3642: 1.87e-6, 559: 6.45e-8, 560: 6.54e-8, 561: 6.96e-8, 6935: 1.13e-9, 5877: 1.01e-9})}
+            5: dict(n=7561, comparable=6964, tight=5406, outside={3642: 1.87e-6, 559: 6.45e-8, 560: 6.54e-8, 561: 6.96e-8, 6935: 1.13e-9, 5877: 1.01e-9}),
+            # second held-out fixture, generated after everything above: the noise class now includes EVERY default-fit candidate (class version 2:
+            # the reference-run studies of seeds 1-5 showed the default fit without migration determined to 1e-9 ... 4e-9 only).  First pass: none outside.
+            6: dict(n=7372, comparable=6805, tight=5112, outside={})}
 
 
 def studied():
@@ -39,7 +43,7 @@ def studied():
     return {(c["campaign"]["seed"], c["campaign"]["model"], c["campaign"]["cand"]) for c in d["cases"]}
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_batches_against_the_oracle(seed):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import random_campaign as rc
