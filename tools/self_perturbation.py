@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """The reference's own indeterminacy for the candidates of the random campaign (CPU only, no GPU).
 
+ROUND 4: the campaign fixtures no longer use this tool's adaptive studies (4 perturbations for the noise class, deepened with --only where the
+device disagreed: rounds 2-3) - tools/uniform_spread.py gives every candidate of the class the same 16 + 16 runs before the device is
+consulted, and every first-pass outlier is run through /root/reference itself (tests/golden/make_golden.py --campaign-only).  This tool
+stays for one-off studies with the ORACLE (`--only`, `--reference`, `--internal`); its side files <fixture>.spread.jsonl (git-ignored)
+are what `tools/uniform_spread.py --validate` compares the baseline's spreads with.
+
 For every candidate of `tools/random_campaign.py` that lies in the noise-driven class (corrected rate x
 interval length >= 5, or default fit with a band or a pulse) the oracle - which reproduces the reference
 bit for bit on the golden cases - is re-run on inputs perturbed by 2^-48 (`tests/parity.py: perturbed`,
@@ -13,16 +19,6 @@ The parity contract (tests/parity.py) then allows the HIP path 10 x that spread 
     python tools/self_perturbation.py --fixture ... --reference --only ...                        # the reference itself (here only)
 
     python tools/self_perturbation.py --fixture ... --internal 16 --only ...                      # one ulp in its own expm instead
-
-Round 4, the protocol fixed in advance (`--uniform K`, K = 16): EVERY candidate of the noise class - rate x length >= 5, default fit
-with a band or a pulse, or "correction failed" in the oracle - gets exactly K input perturbations (kinds 0..K-1) and, where it has a
-value, exactly K one-ulp-in-expm runs (seeds 7000..7000+K-1), computed BEFORE the device is consulted and never deepened afterwards:
-
-    python tools/self_perturbation.py --fixture tests/golden/campaign_seed5.json.gz --uniform 16 --procs 6
-    python tools/self_perturbation.py --fixture tests/golden/campaign_seed5.json.gz --uniform 16 --merge
-
-(--merge --uniform K truncates older, deeper studies of single candidates to their first K runs - the runs are deterministic functions
-of their index - and refuses to write a fixture in which a candidate of the class has fewer.)
 
 Results are appended to <fixture>.spread.jsonl (resumable) and merged into the fixture with --merge:
 every `ref` row becomes [llk, status, rate_x_len, spread, perturbed_runs_failed, kinds] for the candidates
@@ -116,9 +112,9 @@ def internal_job(args):
     return {"i": idx, "internal_runs": runs, "base": base, "vals": out}
 
 
-def noisy_class(c, ref_row, with_failures=False):
+def noisy_class(c, ref_row):
     default_mig = (not c["flags"]["cpfit"]) and (not c["flags"]["true_eps"]) and (len(c["bands"]) > 0 or len(c["pulses"]) > 0)
-    return ref_row[2] >= 5.0 or default_mig or (with_failures and ref_row[1] == 2)
+    return ref_row[2] >= 5.0 or default_mig
 
 
 def load_results(path):
@@ -151,11 +147,7 @@ def main():
     ap.add_argument("--reference", action="store_true", help="run /root/reference itself instead of the oracle (build container only)")
     ap.add_argument("--internal", type=int, default=0, help="instead: this many runs with one-ulp noise in the oracle's pair-chain expm (needs --only)")
     ap.add_argument("--merge", action="store_true", help="fold <fixture>.spread.jsonl into the fixture and exit")
-    ap.add_argument("--uniform", type=int, default=0, help="the fixed protocol: exactly this many input perturbations AND one-ulp-in-expm runs for every "
-                    "candidate of the noise class (failed corrections included); with --merge: truncate every study to that depth")
     a = ap.parse_args()
-    if a.uniform:
-        a.kinds = a.uniform
     USE_REFERENCE = a.reference
     import multiprocessing as mp
     import random_campaign as rc
@@ -176,19 +168,8 @@ def main():
                 have_int[r["i"]] = r
     if a.merge:
         n = 0
-        K = a.uniform
         for i, row in enumerate(d["ref"]):
             row = list(row[:3])
-            in_class = noisy_class(cases[index[i][0]], row, with_failures=True)
-            if K:
-                if not in_class:
-                    d["ref"][i] = row                      # outside the class: clause 1 (1e-9) only, whatever was studied before
-                    continue
-                assert i in have and have[i]["kinds"] >= K, "candidate %d of the noise class has no %d-perturbation study" % (i, K)
-                have[i] = dict(have[i], kinds=K, vals=have[i]["vals"][:K])
-                if row[1] == 0:
-                    assert i in have_int and have_int[i]["internal_runs"] >= K, "candidate %d of the noise class has no %d-run internal study" % (i, K)
-                    have_int[i] = dict(have_int[i], internal_runs=K, vals=have_int[i]["vals"][:K])
             if i in have:
                 spread, nfail, kinds = summarise(have[i], row[0] if row[1] == 0 else None)
                 row += [spread, nfail, kinds]
@@ -198,9 +179,6 @@ def main():
                     fin = [v for v in r["vals"] if v is not None]
                     row += [max(abs(v - row[0]) / abs(row[0]) for v in fin) if fin else None, len(r["vals"]) - len(fin), r["internal_runs"]]
             d["ref"][i] = row
-        if K:
-            d["protocol"] = ("uniform: every candidate with rate x length >= 5, default fit with a band or pulse, or 'correction failed' has exactly %d input "
-                             "perturbations (kinds 0..%d) and, where it has a value, %d one-ulp-in-expm runs; fixed before the device was consulted" % (K, K - 1, K))
         d["spread"] = ("rows of studied candidates: [llk, status, rate x length, spread, perturbed runs without a value, kinds"
                        " (, internal spread, internal runs without a value, internal runs)]; "
                        "tools/self_perturbation.py, perturbations of tests/parity.py")
@@ -211,12 +189,9 @@ def main():
     if a.only:
         todo = [int(i) for i in json.load(open(a.only))]
     else:
-        todo = [i for i, (ci, k) in enumerate(index) if noisy_class(cases[ci], d["ref"][i], with_failures=bool(a.uniform))]
-    if a.uniform and not a.internal:
-        # phase 1 below (input perturbations), then phase 2 (internal) by re-entering with --internal
-        pass
+        todo = [i for i, (ci, k) in enumerate(index) if noisy_class(cases[ci], d["ref"][i])]
     if a.internal:
-        assert (a.only or a.uniform) and not a.reference
+        assert a.only and not a.reference
         todo = [i for i in todo if d["ref"][i][1] == 0 and (i not in have_int or have_int[i]["internal_runs"] < a.internal)]
         print("%d candidates to study with %d noisy-expm runs each (oracle)" % (len(todo), a.internal), file=sys.stderr)
         jobs = [(i, cases[index[i][0]], index[i][1], a.internal, d["ref"][i][0]) for i in todo]
@@ -241,10 +216,6 @@ def main():
                 if n % 200 == 0:
                     print("studied %d / %d" % (n, len(jobs)), file=sys.stderr, flush=True)
     print("done: %s" % side)
-    if a.uniform:
-        import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--fixture", a.fixture, "--uniform", str(a.uniform), "--internal", str(a.uniform), "--procs", str(a.procs)]
-        sys.exit(subprocess.run(cmd).returncode)
 
 
 if __name__ == "__main__":
