@@ -193,6 +193,10 @@ def print_report(rep):
     print(stats)
     print("within 1e-9 (+ rounding floor): %d, worst %.3g" % (stats["tight"], rep["worst_tight"]))
     print("within 10 x the reference's own measured spread under input perturbations: %d, worst factor %.2f" % (stats["self_bound"], rep["worst_factor"]))
+    if rep["factors"]:
+        fs = np.array([f[0] for f in rep["factors"]])
+        print("   distribution of the factor |llk - ref| / spread over those %d: <= 1: %d (%.0f %%), <= 3: %d (%.0f %%), <= 10: all; median %.2f"
+              % (len(fs), (fs <= 1).sum(), 100.0 * (fs <= 1).mean(), (fs <= 3).sum(), 100.0 * (fs <= 3).mean(), float(np.median(fs))))
     for f in rep["factors"][:8]:
         print("   factor %.2f  rel %.3g  spread %.3g  candidate %d (model %d cand %d)" % f)
     print("within 10 x its spread under one ulp in its own pair-chain expm: %d more, worst factor %.2f" % (stats["internal_bound"], rep["worst_internal"]))
