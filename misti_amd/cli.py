@@ -133,10 +133,12 @@ def grid_mode(a, inp, rows):
     finally:
         close()
     dt = time.time() - t0
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:                    # started as a rank (by --gpus N, or by torchrun directly): leave the group in order
         import torch.distributed as tdist
-        tdist.barrier()
-        tdist.destroy_process_group()
+        if tdist.is_initialized():
+            tdist.barrier()
+            tdist.destroy_process_group()
+    if world > 1:
         if rank != 0:
             return 0
         print("Sharded over %d ranks (whole chains per rank; one all_gather of %d x %d log-likelihoods)" % (world, len(split), data.shape[0]))

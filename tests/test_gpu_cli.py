@@ -87,6 +87,17 @@ def test_optimised_band_and_grid(tmp_path):
     rc3, text3 = run_cli([f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "--grid-st", "18", "22",
                           "--grid-mi", "0", "0.001", "0.1", "4", "--all-bs", "--funits", str(tmp_path / "x"), "--gpus", "1"])
     assert rc3 == 0 and rows(text3) == rows(text)
+    # ... and as a rank of a (one-rank) RCCL process group, started the way --gpus N starts its ranks: the group is initialised on the GPU
+    # (backend nccl = RCCL), the sweep runs, the group is left in order
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           "-m", "misti_amd.cli", f1, f2, fj, "20", "-mi", "1", "2", "20", "0.1", "1", "--cpfit", "--grid-st", "18", "22",
+           "--grid-mi", "0", "0.001", "0.1", "4", "--all-bs", "--funits", str(tmp_path / "x")]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, timeout=300, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert rows(r.stdout) == rows(text)
 
 
 def _tokens_match(ours, theirs, rtol):
