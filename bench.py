@@ -361,7 +361,7 @@ def main():
         if strong:
             # ONE grid: whole chains per rank (dist.chain_shards), or interleaved candidates (every chain on every rank)
             sw = a.pretend_world if (a.pretend_world > 1 and world == 1) else world
-            shards = chain_shards(w.params, w.n_cand, sw) if a.shard == "chain" else [shard_indices(w.n_cand, r, sw, interleave=True) for r in range(sw)]
+            shards = chain_shards(w.params, w.n_cand, sw, w.split_time) if a.shard == "chain" else [shard_indices(w.n_cand, r, sw, interleave=True) for r in range(sw)]
             mine = shards[rank]
         else:
             mine = np.arange(w.n_cand)
@@ -619,15 +619,30 @@ def main():
             # both scalings in one line: the headline leg is one of them, the other one here
             other = "strong" if a.scaling == "weak" else "weak"
             extra[a.scaling] = block(main_leg, "the headline leg above")
+
+            def any_rank_failed(failed):
+                # A rank that caught an exception in one leg must not walk into the NEXT leg's collectives while its peers are still
+                # inside this one's (collectives of different sizes would be paired: ADVICE r4): after every leg the ranks agree on
+                # a failure flag, and one failure anywhere skips the remaining collective legs everywhere.  A rank stuck INSIDE a
+                # collective never gets here - that is what the watchdog above is for; it ends every rank with exit status 0 because
+                # the headline line is already valid, and says so in `extra_legs.error` (the driver reads the line, not the status).
+                flag = torch.tensor([1.0 if failed else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                return bool(flag.item() > 0)
+            leg_failed = False
             try:                                   # a secondary leg must never cost the headline line (the same code runs on every rank)
                 o_leg = leg("config5" if other == "strong" else "config2", other, short, min(a.warmup, 16), a.min_seconds, n_streams, serial_pass=False)
                 extra[other] = block(o_leg, "ONE config-5 grid (65 536 candidates, 2 048 chains) sharded over the ranks, %s" % ("whole chains per rank" if a.shard == "chain" else "interleaved") if other == "strong"
                                      else "every rank its own config-2 grid")
             except Exception as e:                 # noqa: BLE001
                 extra[other] = {"error": "%s: %s" % (type(e).__name__, e)}
+                leg_failed = True
+            skip_rest = any_rank_failed(leg_failed)
             # ... and BASELINE config 3 as a search, strong: ONE Nelder-Mead search of 16 384 starts, the starts dealt to the ranks in
             # contiguous blocks, one all_gather of the results (misti_amd.optimize.solve_batched_dev inside the process group)
             try:
+                if skip_rest:
+                    raise RuntimeError("skipped: an earlier secondary leg failed on some rank")
                 from misti_amd.optimize import solve_batched_dev
                 w3 = build_workload("config3", spec)
                 with Engine(w3.times, w3.lh, device=local_rank, **w3.engine_kwargs()) as eng3:

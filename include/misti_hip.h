@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MISTI_ABI_VERSION 4
+#define MISTI_ABI_VERSION 5
 
 /* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
 #define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */
@@ -49,6 +49,7 @@ extern "C" {
 #define MISTI_E_HIP      (-2)  /* HIP runtime error                         */
 #define MISTI_E_NODEV    (-3)  /* no usable HIP device                      */
 #define MISTI_E_LIMIT    (-4)  /* size beyond a compiled-in limit           */
+#define MISTI_E_NOMEM    (-5)  /* out of host memory (a C++ allocation failed; never thrown across the ABI) */
 
 /* per-candidate status (the reference prints a line and returns -inf, or exits) */
 #define MISTI_OK             0
@@ -247,11 +248,14 @@ int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
  * bash loops of test.bs/ (san_sar.bs.sh:29-36) - one OS process per grid point, results concatenated from stdout.
  * Candidates are independent, so there is no exchange between devices during evaluation; what must not be split is a CHAIN:
  * candidates with bitwise identical parameter vectors and band bounds share one lambda-correction chain,
- * computed once per context that holds any of them.  misti_multi_eval_batch therefore deals whole chains to the contexts
- * (round-robin in order of first appearance; a batch without parameters is one chain and is interleaved instead), runs
- * misti_eval_batch on every context at the same time and writes every candidate's rows straight into the caller's buffers:
- * the result is bit for bit that of misti_eval_batch on one device.  Same arguments and conventions as misti_eval_batch.
- * (A process that keeps results on the devices runs one rank per GPU and gathers with RCCL instead: misti_amd/dist.py.) */
+ * computed once per context that holds any of them.  misti_multi_eval_batch therefore deals whole chains to the contexts - the
+ * costliest first, each to the context with the least work so far (a chain costs its length: the corrected two-population
+ * intervals up to the largest split index of its members, + 1/64 per member; chains of equal cost end up round-robin in order of
+ * first appearance; a batch without parameters is one chain and is interleaved instead) -, runs the batch on every context at the
+ * same time (one persistent host thread per context) and gathers / scatters every candidate's rows straight from / into the
+ * caller's buffers: the result is bit for bit that of misti_eval_batch on one device.  Same arguments and conventions as
+ * misti_eval_batch.  A failure on any context - a C++ exception in its worker thread included - fails the call with that
+ * context's message; it never terminates the process. */
 typedef struct misti_multi misti_multi;
 int misti_create_multi(const misti_model_t* model, int n_dev, const int* devices, misti_multi** out);
 int misti_destroy_multi(misti_multi* m);
@@ -261,8 +265,27 @@ int misti_multi_eval_batch(misti_multi* m, int64_t n_cand,
                            const double* split_time, const double* params, const int32_t* band_bounds,
                            int64_t n_rep, const double* jsfs,
                            double* llk, double* jafs, double* lc, double* pr, int32_t* status);
-/* Shards of the last misti_multi_eval_batch: candidates and chains per context ([misti_multi_size] each; either may be NULL). */
+/* Shards of the last misti_multi_eval_batch: candidates and chains per context ([misti_multi_size] each; either may be NULL);
+ * misti_multi_last_cost: the summed chain cost per context (what the dealing balances: they differ by less than one chain). */
 int misti_multi_last_shards(misti_multi* m, int64_t* n_cand, int64_t* n_chain);
+int misti_multi_last_cost(misti_multi* m, double* cost);
+/* Device-resident form with the gather INSIDE the library (RCCL over xGMI).  The caller has sharded its candidates: context i
+ * (device i of the list) evaluates n_cand[i] candidates from DEVICE pointers on its own device, exactly as misti_eval_batch_dev,
+ * and the log-likelihoods are then all-gathered on the devices - ncclAllGather, in place, on a single-process communicator over
+ * the device list (ncclCommInitAll at the first call; every device may be listed once), issued on each context's stream behind
+ * its batch - so that EVERY device ends up with the whole table.  This is what the reference does by concatenating the stdout
+ * of its processes (README.md:113-114), kept in HBM; the rank-per-GPU counterpart is misti_amd/dist.py (torch.distributed).
+ *   n_cand          [D]   candidates of shard i (0 allowed), each <= rows_per_shard
+ *   d_split_time, d_params, d_band_bounds, d_jsfs   [D] host arrays of device pointers (arrays as in misti_eval_batch_dev; d_band_bounds
+ *                         or any of its entries may be NULL; the replicate table d_jsfs[i] [n_rep][8] must be resident on every device)
+ *   d_llk_all       [D]   device i's table [D][rows_per_shard][n_rep]: block r = shard r's rows, rows beyond n_cand[r] NaN
+ *   d_status_all    [D] or NULL   device i's table [D][rows_per_shard] of per-candidate status (-1 beyond n_cand[r])
+ * Asynchronous: returns when everything is issued; misti_multi_sync waits for every context's stream.  librccl.so.1 is bound
+ * at the first call (dlopen by soname: a process that already maps an RCCL - PyTorch-ROCm does - uses that copy). */
+int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t rows_per_shard,
+                               const double* const* d_split_time, const double* const* d_params, const int32_t* const* d_band_bounds,
+                               int64_t n_rep, const double* const* d_jsfs, double* const* d_llk_all, int32_t* const* d_status_all);
+int misti_multi_sync(misti_multi* m);
 /* misti_nm_solve / misti_basinhopping with the starts dealt to the contexts in contiguous blocks, all contexts searching at the
  * same time (BASELINE config 3: 16 384 starts -> 2 048 per GPU on a node).  Starts are independent searches and a start's
  * trajectory does not depend on what else travels in its batches: results equal the single-device call's, start for start.

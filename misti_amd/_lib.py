@@ -21,7 +21,7 @@ STATUS_TEXT = {
     6: "Stiff interval: the contour solver (rate x length > 96) did not converge",
 }
 MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
-ABI_VERSION = 4
+ABI_VERSION = 5
 TRACE_MAX_CAND, TRACE_MAX_ITER = 64, 200
 
 
@@ -85,6 +85,10 @@ SYMBOLS = {
     "misti_multi_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_multi_last_shards": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "misti_multi_last_cost": (C.c_int, [C.c_void_p, _PD]),
+    "misti_multi_eval_batch_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                             C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "misti_multi_sync": (C.c_int, [C.c_void_p]),
     "misti_multi_nm_solve": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_multi_basinhopping": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_int32,

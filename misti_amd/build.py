@@ -71,7 +71,7 @@ def _build_locked(target, verbose, extra):
         cmd += ["-DMISTI_STAMP=1"]
     cmd += ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES]
     tmp = "%s.%d.tmp" % (target, os.getpid())
-    cmd += ["-o", tmp]
+    cmd += ["-o", tmp, "-ldl", "-lpthread"]            # dlopen: RCCL is bound at first use of the gathered multi-device form
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     try:

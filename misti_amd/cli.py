@@ -165,6 +165,12 @@ def grid_mode(a, inp, rows):
 def main(argv=None):
     t0 = time.time()
     a = build_parser().parse_args(argv)
+    # the two ways of using several GPUs exclude each other: N ranks that each opened the whole device list would run N x D contexts
+    if a.gpus > 1 and a.devices:
+        print("--gpus (one rank per GPU) and --devices (a device list in one process) exclude each other", file=sys.stderr)
+        return 2
+    if a.devices and not (a.grid_st or a.grid_mi or a.all_bs):
+        print("--devices applies to the batched sweep (--grid-st / --grid-mi / --all-bs); a single model runs on --device", file=sys.stderr)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not (a.grid_st or a.grid_mi or a.all_bs):
             print("--gpus applies to the batched sweep (--grid-st / --grid-mi / --all-bs); a single model runs on one GPU", file=sys.stderr)

@@ -703,14 +703,8 @@ int misti_argmax_dev(misti_ctx* c, int64_t n_cand, int64_t n_rep, const double* 
 
 namespace {
 int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
-                    double* llk, double* jafs, double* lc, double* pr, int32_t* status);
-}
-
-extern "C" {
-
-int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
-                     double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
-    const int r = eval_batch_host(c, n_cand, split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status);
+                    double* llk, double* jafs, double* lc, double* pr, int32_t* status, const int64_t* idx = nullptr);
+int eval_batch_drained(misti_ctx* c, int r) {
     // An error between the first asynchronous copy and the final wait leaves DMAs reading the context's pinned input block or
     // writing its pinned output block: the next call would overwrite what they read.  Drain the stream before reporting.
     if (r != 0 && c) {
@@ -722,13 +716,36 @@ int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const do
     }
     return r;
 }
+}
+
+extern "C" {
+
+int misti_eval_batch(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
+                     double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
+    return eval_batch_drained(c, eval_batch_host(c, n_cand, split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status));
+}
+
+// misti_eval_batch on the rows idx[0 .. n) of the caller's arrays: inputs are GATHERED from those rows into the context's staging
+// block and every output row i is SCATTERED to row idx[i] - what a context of misti_multi_eval_batch does with its shard of a
+// batch (misti_multi.cpp), without a staging copy of the shard in between.  jsfs is shared (not indexed).  Not part of the public ABI.
+int misti_eval_batch_indexed_(misti_ctx* c, int64_t n, const int64_t* idx, const double* split, const double* params, const int32_t* band_bounds,
+                              int64_t n_rep, const double* jsfs, double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
+    if (!idx) return fail(MISTI_E_ARG, "idx is NULL");
+    try {
+        return eval_batch_drained(c, eval_batch_host(c, n, split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status, idx));
+    } catch (const std::bad_alloc&) {
+        return eval_batch_drained(c, fail(MISTI_E_NOMEM, "out of host memory staging %lld candidates", (long long)n));
+    } catch (const std::exception& e) {
+        return eval_batch_drained(c, fail(MISTI_E_ARG, "%s", e.what()));
+    }
+}
 
 }  // extern "C"
 
 namespace {
 
 int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
-                    double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
+                    double* llk, double* jafs, double* lc, double* pr, int32_t* status, const int64_t* idx) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
@@ -750,20 +767,30 @@ int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const dou
     const bool pinned = in_bytes <= PIN_STAGE_MAX && out_bytes <= PIN_STAGE_MAX &&
                         c->pin_in.reserve(in_bytes) == hipSuccess && c->pin_out.reserve(out_bytes ? out_bytes : 8) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
-    char* hin = pinned ? static_cast<char*>(c->pin_in.p) : nullptr;
-    auto h2d = [&](DevBuf& dst, const void* src, size_t bytes, size_t& off) -> int {
+    // Indexed form (idx: rows of the caller's arrays, misti_eval_batch_indexed_): rows are gathered on the way in and scattered on the
+    // way out; beyond the pinned block's limit the gather goes through pageable heap blocks (std::bad_alloc is the caller's to catch).
+    std::vector<char> heap_in, heap_out;
+    if (idx && !pinned) { heap_in.resize(in_bytes); heap_out.resize(out_bytes ? out_bytes : 8); }
+    char* hin = pinned ? static_cast<char*>(c->pin_in.p) : (idx ? heap_in.data() : nullptr);
+    const bool staged = pinned || idx;
+    // row = bytes per candidate of this array (0: not per candidate - the replicate table)
+    auto h2d = [&](DevBuf& dst, const void* src, size_t bytes, size_t row, size_t& off) -> int {
         if (!bytes) return 0;
         HIP_TRY(dst.reserve(bytes));
         const void* from = src;
-        if (pinned) { std::memcpy(hin + off, src, bytes); from = hin + off; off += bytes; }
+        if (staged) {
+            if (idx && row) for (size_t i = 0; i < nc; ++i) std::memcpy(hin + off + i * row, static_cast<const char*>(src) + (size_t)idx[i] * row, row);
+            else std::memcpy(hin + off, src, bytes);
+            from = hin + off; off += bytes;
+        }
         HIP_TRY(hipMemcpyAsync(dst.p, from, bytes, hipMemcpyHostToDevice, c->stream));
         return 0;
     };
     size_t off = 0;
-    if (int r = h2d(c->st_split, split, b_split, off)) return r;
-    if (int r = h2d(c->st_params, params, b_par, off)) return r;
-    if (int r = h2d(c->st_bounds, band_bounds, b_bounds, off)) return r;
-    if (int r = h2d(c->st_jsfs, jsfs, b_jsfs, off)) return r;
+    if (int r = h2d(c->st_split, split, b_split, sizeof(double), off)) return r;
+    if (int r = h2d(c->st_params, params, b_par, (size_t)P * sizeof(double), off)) return r;
+    if (int r = h2d(c->st_bounds, band_bounds, b_bounds, 2 * (size_t)c->dm.n_band * sizeof(int32_t), off)) return r;
+    if (int r = h2d(c->st_jsfs, jsfs, b_jsfs, 0, off)) return r;
     if (nr) HIP_TRY(c->st_llk.reserve(nc * nr * sizeof(double)));
     HIP_TRY(c->st_jafs.reserve(nc * 7 * sizeof(double)));
     HIP_TRY(c->st_status.reserve(nc * sizeof(int32_t)));
@@ -777,25 +804,28 @@ int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const dou
                     nr ? c->st_jsfs.as<double>() : nullptr, nr ? c->st_llk.as<double>() : nullptr, c->st_jafs.as<double>(),
                     lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
     if (r) return r;
-    char* hout = pinned ? static_cast<char*>(c->pin_out.p) : nullptr;
-    struct Back { void* user; size_t off, bytes; };
+    char* hout = pinned ? static_cast<char*>(c->pin_out.p) : (idx ? heap_out.data() : nullptr);
+    struct Back { void* user; size_t off, bytes, row; };
     Back back[5];
     int n_back = 0;
     size_t ooff = 0;
-    auto d2h = [&](void* user, const void* src, size_t bytes) -> int {
+    auto d2h = [&](void* user, const void* src, size_t bytes, size_t row) -> int {
         if (!bytes) return 0;
         void* to = user;
-        if (pinned) { to = hout + ooff; back[n_back++] = {user, ooff, bytes}; ooff += bytes; }
+        if (staged) { to = hout + ooff; back[n_back++] = {user, ooff, bytes, row}; ooff += bytes; }
         HIP_TRY(hipMemcpyAsync(to, src, bytes, hipMemcpyDeviceToHost, c->stream));
         return 0;
     };
-    if (int q = d2h(llk, c->st_llk.p, b_llk)) return q;
-    if (int q = d2h(jafs, c->st_jafs.p, b_jafs)) return q;
-    if (int q = d2h(lc, c->st_lc.p, b_lc)) return q;
-    if (int q = d2h(pr, c->st_pr.p, b_pr)) return q;
-    if (int q = d2h(status, c->st_status.p, b_status)) return q;
+    if (int q = d2h(llk, c->st_llk.p, b_llk, nr * sizeof(double))) return q;
+    if (int q = d2h(jafs, c->st_jafs.p, b_jafs, 7 * sizeof(double))) return q;
+    if (int q = d2h(lc, c->st_lc.p, b_lc, (size_t)(numT + 1) * 2 * sizeof(double))) return q;
+    if (int q = d2h(pr, c->st_pr.p, b_pr, (size_t)(numT + 2) * 6 * sizeof(double))) return q;
+    if (int q = d2h(status, c->st_status.p, b_status, sizeof(int32_t))) return q;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < n_back; ++i) std::memcpy(back[i].user, hout + back[i].off, back[i].bytes);
+    for (int i = 0; i < n_back; ++i) {
+        if (idx) for (size_t k = 0; k < nc; ++k) std::memcpy(static_cast<char*>(back[i].user) + (size_t)idx[k] * back[i].row, hout + back[i].off + k * back[i].row, back[i].row);
+        else std::memcpy(back[i].user, hout + back[i].off, back[i].bytes);
+    }
     return 0;
 }
 

@@ -1,41 +1,198 @@
 // Multi-device form of the C ABI (include/misti_hip.h, "several devices"): SURVEY 8b's "variant taking a device list for
 // 1/2/4/8-GPU runs".  Replaces the reference's way of using more than one processor - `parallel -j 20 ... >> res.out`,
 // /root/reference/README.md:110-115, and the bash loops of test.bs/*.sh: one OS process per grid point, results concatenated
-// from stdout - for a caller that binds the C ABI from ONE process: one engine context and one host thread per listed device
-// (a device may be listed more than once), candidates dealt out by whole lambda-correction CHAINS, results written straight
-// into the caller's buffers.  No exchange between devices during evaluation (candidates are independent); no collective either:
-// the host-buffer form ends in host memory, which every device's DMA engine reaches by itself.  (Processes that keep their
-// results on the devices use one rank per GPU and an RCCL all_gather instead: misti_amd/dist.py.)
+// from stdout - for a caller that binds the C ABI from ONE process: one engine context and one PERSISTENT host thread per listed
+// device (a device may be listed more than once), candidates dealt out by whole lambda-correction CHAINS, the costliest first.
 //
-// Built on the public single-device entry points only (misti_create, misti_eval_batch, misti_nm_solve, misti_basinhopping).
+//   misti_multi_eval_batch      host buffers in and out: every context gathers its rows straight from / scatters them straight
+//                               into the caller's arrays (no exchange between devices, no collective: the results end in host
+//                               memory, which every device's DMA engine reaches by itself);
+//   misti_multi_eval_batch_dev  device buffers in and out, one shard per context, and the log-likelihoods GATHERED ON THE DEVICES
+//                               by RCCL (ncclAllGather over xGMI on a single-process communicator over the device list): the
+//                               in-library counterpart of the rank-per-GPU path of misti_amd/dist.py - the reference concatenates
+//                               the stdout of its processes (README.md:113-114).
+//
+// No C++ exception leaves this file: every entry point and every worker body runs inside guarded() (include/misti_hip.h:20-21).
+// Built on the public single-device entry points (+ the indexed host-buffer form misti_eval_batch_indexed_, misti_api.cpp).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <numeric>
 #include <string>
 #include <thread>
 #include <unordered_map>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/misti_hip.h"
 
 extern "C" int misti_set_error_(int code, const char* msg);     // misti_api.cpp: sets the calling thread's misti_last_error
-
-struct misti_multi {
-    std::vector<misti_ctx*> ctx;
-    std::vector<int> device;
-    int n_param = 0, n_band = 0, numT = 0;
-    std::vector<int64_t> last_cands, last_chains;        // shard sizes of the last misti_multi_eval_batch
-};
+// misti_eval_batch on the rows idx[0 .. n) of the caller's arrays (gathered into the context's pinned block, results scattered
+// back to rows idx[i]): no staging copy in between.  misti_api.cpp; not part of the public ABI.
+extern "C" int misti_eval_batch_indexed_(misti_ctx* ctx, int64_t n, const int64_t* idx, const double* split, const double* params,
+                                         const int32_t* band_bounds, int64_t n_rep, const double* jsfs,
+                                         double* llk, double* jafs, double* lc, double* pr, int32_t* status);
 
 namespace {
 
 int failm(int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[640];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     return misti_set_error_(code, buf);
+}
+
+// fn() -> int with every exception turned into an error code + message (never across the ABI, never out of a thread)
+template <class F>
+int guarded(const char* where, F&& fn) noexcept {
+    try {
+        return fn();
+    } catch (const std::bad_alloc&) {
+        return failm(MISTI_E_NOMEM, "%s: out of host memory", where);
+    } catch (const std::exception& e) {
+        return failm(MISTI_E_ARG, "%s: %s", where, e.what());
+    } catch (...) {
+        return failm(MISTI_E_ARG, "%s: unknown C++ exception", where);
+    }
+}
+
+// ---- RCCL, bound at first use ------------------------------------------------------------------------------------------------
+// dlopen by soname: a process that already carries an RCCL (PyTorch-ROCm maps its own librccl.so.1) gets THAT one, never a second
+// copy; a plain C caller gets the system's.  Only the handful of entry points the gather needs; types from the published ABI
+// (rccl.h: ncclResult_t 0 = success; ncclInt32 = 2, ncclFloat64 = 8).
+struct Rccl {
+    void* handle = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    std::string why;
+};
+constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8;
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) { const char* e = dlerror(); r.why = std::string("librccl.so.1 cannot be loaded: ") + (e ? e : "?"); return; }
+        auto sym = [&](const char* n) -> void* {
+            void* p = dlsym(r.handle, n);
+            if (!p && r.why.empty()) r.why = std::string("RCCL lacks ") + n;
+            return p;
+        };
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    });
+    return &r;
+}
+
+}  // namespace
+
+// ---- the object ----------------------------------------------------------------------------------------------------------------
+struct misti_multi {
+    std::vector<misti_ctx*> ctx;
+    std::vector<int> device;
+    int n_param = 0, n_band = 0, numT = 0;
+    std::vector<int64_t> last_cands, last_chains;        // shard sizes of the last misti_multi_eval_batch
+    std::vector<double> last_cost;                       // ... and the summed chain cost per context (what the dealing balances)
+    std::vector<std::vector<int64_t>> shard;             // candidate rows per context (kept between calls: no allocation in steady state)
+    std::vector<void*> comm;                             // RCCL communicators, one per context (created by the first _dev call)
+    int throw_in_worker = -1;                            // test hook (MISTI_MULTI_THROW_IN_WORKER, read once in misti_create_multi)
+
+    // persistent workers: thread d serves context d
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    const std::function<int(int)>* job = nullptr;
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+
+    void worker(int d) noexcept {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<int(int)>* fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                fn = job;
+            }
+            const int r = guarded("worker thread", [&] { return (*fn)(d); });
+            std::string why;
+            if (r != 0) { try { why = misti_last_error(); } catch (...) {} }     // thread-local in the worker: carry it over
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                rc[d] = r;
+                msg[d].swap(why);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void shutdown() noexcept {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+
+namespace {
+
+// run fn(d) for every context at the same time, each on its own persistent thread; returns the first failure (its message
+// becomes the caller's misti_last_error)
+int on_every_device(misti_multi* m, const std::function<int(int)>& fn) {
+    const int D = (int)m->ctx.size();
+    if (D == 1) {
+        const int r = guarded("misti_multi", [&] { return fn(0); });
+        if (r != 0) { const std::string why = misti_last_error(); return failm(r, "device %d (context 0 of 1): %s", m->device[0], why.c_str()); }
+        return 0;
+    }
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->job = &fn;
+        m->pending = D;
+        std::fill(m->rc.begin(), m->rc.end(), 0);
+        ++m->generation;
+        m->cv_go.notify_all();
+        m->cv_done.wait(lk, [&] { return m->pending == 0; });
+        m->job = nullptr;
+    }
+    for (int d = 0; d < D; ++d)
+        if (m->rc[d] != 0) return failm(m->rc[d], "device %d (context %d of %d): %s", m->device[d], d, D, m->msg[d].c_str());
+    return 0;
+}
+
+// contiguous blocks of starts: block d = [lo[d], lo[d + 1])
+std::vector<int64_t> blocks(int64_t n, int D) {
+    std::vector<int64_t> lo(D + 1);
+    for (int d = 0; d <= D; ++d) lo[d] = n * d / D;
+    return lo;
 }
 
 // key of a candidate's chain: the bits of its parameter vector and of its band bounds (setup_kernel keys its table the same way)
@@ -52,33 +209,67 @@ struct KeyHash {
     }
 };
 
-// run fn(d) on one host thread per context; returns the first failure (its message becomes the caller's misti_last_error)
-template <class F>
-int on_every_device(misti_multi* m, F fn) {
-    const int D = (int)m->ctx.size();
-    std::vector<int> rc(D, 0);
-    std::vector<std::string> msg(D);
-    auto work = [&](int d) {
-        rc[d] = fn(d);
-        if (rc[d] != 0) msg[d] = misti_last_error();         // thread-local in the worker: carry it over
-    };
-    if (D == 1) work(0);
-    else {
-        std::vector<std::thread> th;
-        th.reserve(D);
-        for (int d = 0; d < D; ++d) th.emplace_back(work, d);
-        for (auto& t : th) t.join();
-    }
-    for (int d = 0; d < D; ++d)
-        if (rc[d] != 0) return failm(rc[d], "device %d (context %d of %d): %s", m->device[d], d, D, msg[d].c_str());
-    return 0;
-}
+// ---- whole chains per device, the costliest first ----------------------------------------------------------------------------
+// Candidates with identical parameter vectors and band bounds share one lambda-correction chain, computed once per context that
+// holds any of them, at its full latency however few members that context has: a chain stays on ONE device, all its split times
+// with it.  What a chain costs is known on the host: its LENGTH - the corrected two-population intervals up to the largest split
+// index of its members (the solver walks them one after the other; a post-split interval is a closed form) - plus a little per
+// member (the spectrum kernel).  Longest-processing-time-first: chains by descending cost (ties: first appearance), each to the
+// context with the least cost so far (ties: lowest index) - within 4/3 of the optimal makespan, and a grid whose chains all cost
+// the same is dealt round-robin as before.  misti_amd/dist.py: chain_shards deals the ranks of the rank-per-GPU path the same way.
+// Without parameters and bounds the batch is one chain: candidates are interleaved instead (every device repeats the chain; what
+// is shared out is the spectrum kernel and the replicate epilogue).
+constexpr double MEMBER_COST = 1.0 / 64.0;
 
-// contiguous blocks of starts: block d = [lo[d], lo[d + 1])
-std::vector<int64_t> blocks(int64_t n, int D) {
-    std::vector<int64_t> lo(D + 1);
-    for (int d = 0; d <= D; ++d) lo[d] = n * d / D;
-    return lo;
+void deal_chains(misti_multi* m, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds) {
+    const int D = (int)m->ctx.size(), P = m->n_param, B = m->n_band;
+    const bool with_bounds = band_bounds && B > 0;
+    const size_t kp = (size_t)P * sizeof(double), kb = with_bounds ? (size_t)B * 2 * sizeof(int32_t) : 0, kl = kp + kb;
+    for (int d = 0; d < D; ++d) { m->shard[d].clear(); m->last_cands[d] = m->last_chains[d] = 0; m->last_cost[d] = 0.0; }
+    if (kl == 0) {
+        for (int64_t c = 0; c < n_cand; ++c) m->shard[c % D].push_back(c);
+        for (int d = 0; d < D; ++d) { m->last_chains[d] = m->shard[d].empty() ? 0 : 1; m->last_cands[d] = (int64_t)m->shard[d].size(); }
+        return;
+    }
+    std::vector<char> keys((size_t)n_cand * kl);
+    for (int64_t c = 0; c < n_cand; ++c) {
+        char* k = keys.data() + (size_t)c * kl;
+        if (kp) std::memcpy(k, params + (size_t)c * P, kp);
+        if (kb) std::memcpy(k + kp, band_bounds + (size_t)c * B * 2, kb);
+    }
+    std::unordered_map<Key, int32_t, KeyHash> chain_of_key;
+    chain_of_key.reserve((size_t)n_cand / 4 + 16);
+    std::vector<int32_t> chain(n_cand);
+    std::vector<double> len;                              // per chain: largest split index of its members
+    std::vector<int64_t> members;
+    for (int64_t c = 0; c < n_cand; ++c) {
+        const Key k{keys.data() + (size_t)c * kl, kl};
+        auto it = chain_of_key.find(k);
+        int32_t ch;
+        if (it == chain_of_key.end()) { ch = (int32_t)len.size(); chain_of_key.emplace(k, ch); len.push_back(0.0); members.push_back(0); }
+        else ch = it->second;
+        chain[c] = ch;
+        members[ch] += 1;
+        const double s = split[c];
+        const double l = (s == s && s > 0.0) ? std::ceil(std::min(s, (double)m->numT)) : 0.0;     // a fractional split adds its shortened interval
+        if (l > len[ch]) len[ch] = l;
+    }
+    const size_t nch = len.size();
+    std::vector<double> cost(nch);
+    for (size_t i = 0; i < nch; ++i) cost[i] = len[i] + MEMBER_COST * (double)members[i];
+    std::vector<int32_t> order(nch);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cost[a] > cost[b]; });
+    std::vector<int> owner(nch);
+    for (int32_t ch : order) {
+        int best = 0;
+        for (int d = 1; d < D; ++d) if (m->last_cost[d] < m->last_cost[best]) best = d;
+        owner[ch] = best;
+        m->last_cost[best] += cost[ch];
+        m->last_chains[best] += 1;
+    }
+    for (int64_t c = 0; c < n_cand; ++c) m->shard[owner[chain[c]]].push_back(c);
+    for (int d = 0; d < D; ++d) m->last_cands[d] = (int64_t)m->shard[d].size();
 }
 
 }  // namespace
@@ -92,29 +283,50 @@ int misti_create_multi(const misti_model_t* model, int n_dev, const int* devices
     if (have < 1) return failm(MISTI_E_NODEV, "no usable HIP device");
     for (int d = 0; d < n_dev; ++d)
         if (devices[d] < 0 || devices[d] >= have) return failm(MISTI_E_ARG, "device %d is not one of the %d visible HIP devices", devices[d], have);
-    misti_multi* m = new misti_multi;
-    m->n_param = model->n_param; m->n_band = model->n_band; m->numT = model->numT;
-    for (int d = 0; d < n_dev; ++d) {
-        misti_ctx* c = nullptr;
-        const int r = misti_create(model, devices[d], &c);
-        if (r != 0) {
+    misti_multi* m = nullptr;
+    const int r = guarded("misti_create_multi", [&]() -> int {
+        m = new misti_multi;
+        m->n_param = model->n_param; m->n_band = model->n_band; m->numT = model->numT;
+        for (int d = 0; d < n_dev; ++d) {
+            misti_ctx* c = nullptr;
+            const int q = misti_create(model, devices[d], &c);
+            if (q != 0) { const std::string why = misti_last_error(); return failm(q, "device %d: %s", devices[d], why.c_str()); }
+            m->ctx.push_back(c);
+            m->device.push_back(devices[d]);
+        }
+        m->last_cands.assign(n_dev, 0);
+        m->last_chains.assign(n_dev, 0);
+        m->last_cost.assign(n_dev, 0.0);
+        m->shard.resize(n_dev);
+        m->rc.assign(n_dev, 0);
+        m->msg.resize(n_dev);
+        if (const char* e = std::getenv("MISTI_MULTI_THROW_IN_WORKER")) m->throw_in_worker = std::atoi(e);   // tests: a worker that throws must fail the call, not the process
+        if (n_dev > 1) {
+            m->th.reserve(n_dev);
+            for (int d = 0; d < n_dev; ++d) m->th.emplace_back([m, d] { m->worker(d); });     // a failure here joins the threads already started (below)
+        }
+        return 0;
+    });
+    if (r != 0) {
+        if (m) {
             const std::string why = misti_last_error();
+            m->shutdown();
             for (misti_ctx* q : m->ctx) (void)misti_destroy(q);
             delete m;
-            return failm(r, "device %d: %s", devices[d], why.c_str());
+            return failm(r, "%s", why.c_str());
         }
-        m->ctx.push_back(c);
-        m->device.push_back(devices[d]);
+        return r;
     }
-    m->last_cands.assign(n_dev, 0);
-    m->last_chains.assign(n_dev, 0);
     *out = m;
     return 0;
 }
 
 int misti_destroy_multi(misti_multi* m) {
     if (!m) return 0;
+    m->shutdown();
     int rc = 0;
+    Rccl* R = rccl();
+    for (void* c : m->comm) if (c && R->CommDestroy) (void)R->CommDestroy(c);
     for (misti_ctx* c : m->ctx) { const int r = misti_destroy(c); if (r != 0 && rc == 0) rc = r; }
     delete m;
     return rc;
@@ -138,78 +350,111 @@ int misti_multi_last_shards(misti_multi* m, int64_t* n_cand, int64_t* n_chain) {
     return 0;
 }
 
+int misti_multi_last_cost(misti_multi* m, double* cost) {
+    if (!m || !cost) return failm(MISTI_E_ARG, "multi context / cost is NULL");
+    for (size_t d = 0; d < m->ctx.size(); ++d) cost[d] = m->last_cost[d];
+    return 0;
+}
+
+int misti_multi_sync(misti_multi* m) {
+    if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
+    for (size_t d = 0; d < m->ctx.size(); ++d) {
+        const int r = misti_sync(m->ctx[d]);
+        if (r != 0) { const std::string why = misti_last_error(); return failm(r, "device %d (context %d): %s", m->device[d], (int)d, why.c_str()); }
+    }
+    return 0;
+}
+
 int misti_multi_eval_batch(misti_multi* m, int64_t n_cand, const double* split, const double* params, const int32_t* band_bounds,
                            int64_t n_rep, const double* jsfs, double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
     if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
     if (n_cand < 0 || n_rep < 0) return failm(MISTI_E_ARG, "negative batch size");
     const int D = (int)m->ctx.size();
-    for (int d = 0; d < D; ++d) m->last_cands[d] = m->last_chains[d] = 0;
+    for (int d = 0; d < D; ++d) { m->last_cands[d] = m->last_chains[d] = 0; m->last_cost[d] = 0.0; }
     if (n_cand == 0) return 0;
     if (!split) return failm(MISTI_E_ARG, "split_time is NULL");
-    const int P = m->n_param, B = m->n_band, numT = m->numT;
+    const int P = m->n_param;
     if (P > 0 && !params) return failm(MISTI_E_ARG, "params is NULL but the model has %d parameters", P);
     if (n_rep > 0 && (!jsfs || !llk)) return failm(MISTI_E_ARG, "jsfs / llk is NULL with n_rep > 0");
     if (D == 1) {
         m->last_cands[0] = n_cand;
         return misti_eval_batch(m->ctx[0], n_cand, split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status);
     }
-    // ---- whole chains per device -----------------------------------------------------------------------------------------
-    // Candidates with identical parameter vectors and band bounds share one lambda-correction chain, computed once per context
-    // that holds any of them, at its full latency however few members that context has: a chain stays on ONE device, all its
-    // split times with it.  Chains are dealt round-robin in order of first appearance (misti_amd/dist.py: chain_shards - the
-    // rank-per-GPU path deals them the same way).  Without parameters and bounds the batch is one chain: candidates are
-    // interleaved instead (every device repeats the chain; what is shared out is the spectrum kernel and the replicate epilogue).
-    const bool with_bounds = band_bounds && B > 0;
-    const size_t kp = (size_t)P * sizeof(double), kb = with_bounds ? (size_t)B * 2 * sizeof(int32_t) : 0;
-    std::vector<std::vector<int64_t>> shard(D);
-    if (kp + kb == 0) {
-        for (int64_t c = 0; c < n_cand; ++c) shard[c % D].push_back(c);
-        for (int d = 0; d < D; ++d) m->last_chains[d] = shard[d].empty() ? 0 : 1;
-    } else {
-        std::vector<char> keys((size_t)n_cand * (kp + kb));
-        for (int64_t c = 0; c < n_cand; ++c) {
-            char* k = keys.data() + (size_t)c * (kp + kb);
-            if (kp) std::memcpy(k, params + (size_t)c * P, kp);
-            if (kb) std::memcpy(k + kp, band_bounds + (size_t)c * B * 2, kb);
-        }
-        std::unordered_map<Key, int, KeyHash> owner;
-        owner.reserve((size_t)n_cand / 4 + 16);
-        int next = 0;
-        for (int64_t c = 0; c < n_cand; ++c) {
-            const Key k{keys.data() + (size_t)c * (kp + kb), kp + kb};
-            auto it = owner.find(k);
-            int d;
-            if (it == owner.end()) { d = next % D; ++next; owner.emplace(k, d); m->last_chains[d] += 1; }
-            else d = it->second;
-            shard[d].push_back(c);
-        }
+    return guarded("misti_multi_eval_batch", [&]() -> int {
+        deal_chains(m, n_cand, split, params, band_bounds);
+        const std::function<int(int)> fn = [&](int d) -> int {
+            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            const std::vector<int64_t>& idx = m->shard[d];
+            if (idx.empty()) return 0;
+            // rows idx[] of the caller's arrays: gathered into / scattered from the context's pinned block (disjoint rows: no two threads share one)
+            return misti_eval_batch_indexed_(m->ctx[d], (int64_t)idx.size(), idx.data(), split, params, band_bounds, n_rep, jsfs, llk, jafs, lc, pr, status);
+        };
+        return on_every_device(m, fn);
+    });
+}
+
+// Device-resident form: context i evaluates ITS shard (device pointers on device i, as misti_eval_batch_dev) and the
+// log-likelihoods are gathered on the devices: ncclAllGather (RCCL over xGMI), in place, on each context's stream, behind its batch.
+int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t rows_per_shard,
+                               const double* const* d_split_time, const double* const* d_params, const int32_t* const* d_band_bounds,
+                               int64_t n_rep, const double* const* d_jsfs, double* const* d_llk_all, int32_t* const* d_status_all) {
+    if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
+    if (!n_cand || !d_split_time || !d_llk_all || !d_jsfs) return failm(MISTI_E_ARG, "n_cand / d_split_time / d_jsfs / d_llk_all is NULL");
+    if (n_rep < 1) return failm(MISTI_E_ARG, "the gathered form needs at least one replicate");
+    const int D = (int)m->ctx.size(), P = m->n_param;
+    if (P > 0 && !d_params) return failm(MISTI_E_ARG, "d_params is NULL but the model has %d parameters", P);
+    for (int d = 0; d < D; ++d) {
+        if (n_cand[d] < 0 || n_cand[d] > rows_per_shard) return failm(MISTI_E_ARG, "shard %d: %lld candidates do not fit rows_per_shard = %lld", d, (long long)n_cand[d], (long long)rows_per_shard);
+        if (!d_llk_all[d] || !d_jsfs[d] || (n_cand[d] > 0 && (!d_split_time[d] || (P > 0 && !d_params[d])))) return failm(MISTI_E_ARG, "shard %d: a device pointer is NULL", d);
+        if (d_status_all && !d_status_all[d]) return failm(MISTI_E_ARG, "shard %d: d_status_all is NULL", d);
+        for (int e = 0; e < d; ++e)
+            if (m->device[e] == m->device[d]) return failm(MISTI_E_ARG, "device %d is listed twice: an RCCL communicator holds every device once", m->device[d]);
     }
-    for (int d = 0; d < D; ++d) m->last_cands[d] = (int64_t)shard[d].size();
-    const size_t R = (size_t)n_rep, lc_row = (size_t)(numT + 1) * 2, pr_row = (size_t)(numT + 2) * 6;
-    return on_every_device(m, [&](int d) -> int {
-        const std::vector<int64_t>& idx = shard[d];
-        const size_t n = idx.size();
-        if (n == 0) return 0;
-        std::vector<double> s(n), p(kp ? n * (size_t)P : 0), o_llk(R ? n * R : 0), o_jafs(jafs ? n * 7 : 0), o_lc(lc ? n * lc_row : 0), o_pr(pr ? n * pr_row : 0);
-        std::vector<int32_t> b(kb ? n * (size_t)B * 2 : 0), o_st(status ? n : 0);
-        for (size_t i = 0; i < n; ++i) {
-            const size_t c = (size_t)idx[i];
-            s[i] = split[c];
-            if (kp) std::memcpy(&p[i * P], params + c * P, kp);
-            if (kb) std::memcpy(&b[i * B * 2], band_bounds + c * B * 2, kb);
+    if (rows_per_shard == 0) return 0;
+    return guarded("misti_multi_eval_batch_dev", [&]() -> int {
+        Rccl* R = rccl();
+        if (!R->handle || !R->why.empty()) return failm(MISTI_E_NODEV, "%s", R->why.c_str());
+        if (m->comm.empty()) {
+            // one communicator over the device list, created once per multi context (ncclCommInitAll: all ranks in this process)
+            std::vector<void*> comms(D, nullptr);
+            const int q = R->CommInitAll(comms.data(), D, m->device.data());
+            if (q != 0) return failm(MISTI_E_HIP, "ncclCommInitAll over %d devices: %s", D, R->GetErrorString(q));
+            m->comm = comms;
         }
-        const int r = misti_eval_batch(m->ctx[d], (int64_t)n, s.data(), kp ? p.data() : nullptr, kb ? b.data() : nullptr, n_rep, jsfs,
-                                       R ? o_llk.data() : nullptr, jafs ? o_jafs.data() : nullptr, lc ? o_lc.data() : nullptr,
-                                       pr ? o_pr.data() : nullptr, status ? o_st.data() : nullptr);
-        if (r != 0) return r;
-        for (size_t i = 0; i < n; ++i) {                       // disjoint rows of the caller's buffers: no two threads share one
-            const size_t c = (size_t)idx[i];
-            if (R) std::memcpy(llk + c * R, &o_llk[i * R], R * sizeof(double));
-            if (jafs) std::memcpy(jafs + c * 7, &o_jafs[i * 7], 7 * sizeof(double));
-            if (lc) std::memcpy(lc + c * lc_row, &o_lc[i * lc_row], lc_row * sizeof(double));
-            if (pr) std::memcpy(pr + c * pr_row, &o_pr[i * pr_row], pr_row * sizeof(double));
-            if (status) status[c] = o_st[i];
+        const size_t blk = (size_t)rows_per_shard * (size_t)n_rep;
+        // every context issues its batch at the same time (a launch sequence costs the host ~50 us per batch): context d writes its
+        // rows straight into block d of ITS gathered table, the rows beyond its shard are NaN (all-ones bytes)
+        const std::function<int(int)> fn = [&](int d) -> int {
+            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            void* sv = nullptr;
+            if (int q = misti_get_stream(m->ctx[d], &sv)) return q;
+            hipStream_t s = static_cast<hipStream_t>(sv);
+            if (hipSetDevice(m->device[d]) != hipSuccess) return failm(MISTI_E_HIP, "hipSetDevice(%d) failed", m->device[d]);
+            double* mine = d_llk_all[d] + (size_t)d * blk;
+            const size_t used = (size_t)n_cand[d] * (size_t)n_rep;
+            if (used < blk && hipMemsetAsync(mine + used, 0xFF, (blk - used) * sizeof(double), s) != hipSuccess) return failm(MISTI_E_HIP, "hipMemsetAsync failed");
+            int32_t* st = d_status_all ? d_status_all[d] + (size_t)d * (size_t)rows_per_shard : nullptr;
+            if (st && n_cand[d] < rows_per_shard &&
+                hipMemsetAsync(st + n_cand[d], 0xFF, (size_t)(rows_per_shard - n_cand[d]) * sizeof(int32_t), s) != hipSuccess) return failm(MISTI_E_HIP, "hipMemsetAsync failed");
+            if (n_cand[d] == 0) return 0;
+            return misti_eval_batch_dev(m->ctx[d], n_cand[d], d_split_time[d], P > 0 ? d_params[d] : nullptr, d_band_bounds ? d_band_bounds[d] : nullptr,
+                                        n_rep, d_jsfs[d], mine, nullptr, nullptr, nullptr, st);
+        };
+        if (int q = on_every_device(m, fn)) return q;
+        // ONE grouped collective for all ranks of this process (a single thread drives every communicator: ncclGroupStart / End)
+        int q = R->GroupStart();
+        for (int d = 0; d < D && q == 0; ++d) {
+            void* sv = nullptr;
+            if (int e = misti_get_stream(m->ctx[d], &sv)) { (void)R->GroupEnd(); return e; }
+            hipStream_t s = static_cast<hipStream_t>(sv);
+            q = R->AllGather(d_llk_all[d] + (size_t)d * blk, d_llk_all[d], blk, NCCL_FLOAT64, m->comm[d], s);
+            if (q == 0 && d_status_all)
+                q = R->AllGather(d_status_all[d] + (size_t)d * (size_t)rows_per_shard, d_status_all[d], (size_t)rows_per_shard, NCCL_INT32, m->comm[d], s);
         }
+        const int qe = R->GroupEnd();
+        if (q == 0) q = qe;
+        if (q != 0) return failm(MISTI_E_HIP, "ncclAllGather: %s", R->GetErrorString(q));
+        for (int d = 0; d < D; ++d) m->last_cands[d] = n_cand[d];
         return 0;
     });
 }
@@ -222,13 +467,17 @@ int misti_multi_nm_solve(misti_multi* m, int64_t n_start, const double* starts, 
     if (n_start < 0) return failm(MISTI_E_ARG, "negative number of starts");
     if (n_start == 0) return 0;
     if (!starts || !jsfs_row || !x || !llh) return failm(MISTI_E_ARG, "starts / jsfs_row / x / llh is NULL");
-    const int D = (int)m->ctx.size(), N = m->n_param;
-    const std::vector<int64_t> lo = blocks(n_start, D);
-    return on_every_device(m, [&](int d) -> int {
-        const int64_t a = lo[d], n = lo[d + 1] - lo[d];
-        if (n == 0) return 0;
-        return misti_nm_solve(m->ctx[d], n, starts + a * N, split_time, jsfs_row, xatol, fatol, maxiter, x + a * N, llh + a,
-                              nit ? nit + a : nullptr, nfev ? nfev + a : nullptr, status ? status + a : nullptr);
+    return guarded("misti_multi_nm_solve", [&]() -> int {
+        const int D = (int)m->ctx.size(), N = m->n_param;
+        const std::vector<int64_t> lo = blocks(n_start, D);
+        const std::function<int(int)> fn = [&](int d) -> int {
+            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            const int64_t a = lo[d], n = lo[d + 1] - lo[d];
+            if (n == 0) return 0;
+            return misti_nm_solve(m->ctx[d], n, starts + a * N, split_time, jsfs_row, xatol, fatol, maxiter, x + a * N, llh + a,
+                                  nit ? nit + a : nullptr, nfev ? nfev + a : nullptr, status ? status + a : nullptr);
+        };
+        return on_every_device(m, fn);
     });
 }
 
@@ -240,15 +489,19 @@ int misti_multi_basinhopping(misti_multi* m, int64_t n_start, const double* star
     if (n_start < 0 || niter < 0) return failm(MISTI_E_ARG, "negative number of starts / hops");
     if (n_start == 0) return 0;
     if (!starts || !jsfs_row || !x || !llh || (niter > 0 && !uniforms)) return failm(MISTI_E_ARG, "starts / jsfs_row / uniforms / x / llh is NULL");
-    const int D = (int)m->ctx.size(), N = m->n_param;
-    const std::vector<int64_t> lo = blocks(n_start, D);
-    const int64_t per_start = (int64_t)niter * (N + 1);
-    return on_every_device(m, [&](int d) -> int {
-        const int64_t a = lo[d], n = lo[d + 1] - lo[d];
-        if (n == 0) return 0;
-        return misti_basinhopping(m->ctx[d], n, starts + a * N, split_time, jsfs_row, niter, T, stepsize, interval, target_accept_rate, stepwise_factor,
-                                  xatol, fatol, nm_maxiter, nm_maxfev, uniforms ? uniforms + a * per_start : nullptr, x + a * N, llh + a,
-                                  nfev ? nfev + a : nullptr, failures ? failures + a : nullptr, accepted ? accepted + a : nullptr);
+    return guarded("misti_multi_basinhopping", [&]() -> int {
+        const int D = (int)m->ctx.size(), N = m->n_param;
+        const std::vector<int64_t> lo = blocks(n_start, D);
+        const int64_t per_start = (int64_t)niter * (N + 1);
+        const std::function<int(int)> fn = [&](int d) -> int {
+            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            const int64_t a = lo[d], n = lo[d + 1] - lo[d];
+            if (n == 0) return 0;
+            return misti_basinhopping(m->ctx[d], n, starts + a * N, split_time, jsfs_row, niter, T, stepsize, interval, target_accept_rate, stepwise_factor,
+                                      xatol, fatol, nm_maxiter, nm_maxfev, uniforms ? uniforms + a * per_start : nullptr, x + a * N, llh + a,
+                                      nfev ? nfev + a : nullptr, failures ? failures + a : nullptr, accepted ? accepted + a : nullptr);
+        };
+        return on_every_device(m, fn);
     });
 }
 

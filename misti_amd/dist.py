@@ -37,22 +37,61 @@ def padded_count(n, world):
     return -(-n // world)
 
 
-def chain_shards(params, n, world):
+MEMBER_COST = 1.0 / 64.0      # cost of one member of a chain (spectrum kernel) in units of one corrected interval (misti_multi.cpp)
+
+
+def chain_costs(params, n, split_time=None, band_bounds=None, numT=None):
+    """Chains of a batch and what each costs.  Candidates with bitwise identical parameter vectors (and band bounds) share one
+    lambda-correction chain; a chain costs its LENGTH - the corrected two-population intervals up to the largest split index of
+    its members, ``ceil(split)``: a fractional split adds its shortened interval - plus ``MEMBER_COST`` per member.  Without
+    ``split_time`` every chain costs the same.  Returns ``(chain_of_candidate[n], cost[n_chain])``, chains numbered in order of
+    first appearance."""
+    p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(n, -1))
+    key = p.view(np.uint8).reshape(n, -1)
+    if band_bounds is not None:
+        key = np.concatenate([key, np.ascontiguousarray(band_bounds, dtype=np.int32).reshape(n, -1).view(np.uint8).reshape(n, -1)], axis=1)
+    key = np.ascontiguousarray(key)
+    _, first, inverse = np.unique(key.view(np.dtype((np.void, key.shape[1]))).ravel(), return_index=True, return_inverse=True)
+    rank_by_first = np.empty(len(first), dtype=np.int64)
+    rank_by_first[np.argsort(first, kind="stable")] = np.arange(len(first))
+    chain = rank_by_first[inverse.ravel()]
+    members = np.bincount(chain, minlength=len(first)).astype(np.float64)
+    length = np.zeros(len(first))
+    if split_time is not None:
+        st = np.asarray(split_time, dtype=np.float64).reshape(n)
+        ln = np.where((st == st) & (st > 0), np.ceil(np.minimum(st, np.inf if numT is None else float(numT))), 0.0)
+        np.maximum.at(length, chain, ln)
+    return chain, length + MEMBER_COST * members
+
+
+def deal_lpt(cost, world):
+    """Longest-processing-time-first: items by descending cost (ties: lowest index), each to the bin with the least cost so far
+    (ties: lowest bin).  Returns ``owner[len(cost)]``.  Within 4/3 of the optimal makespan; equal costs deal round-robin."""
+    load = np.zeros(world)
+    owner = np.empty(len(cost), dtype=np.int64)
+    for i in np.argsort(-np.asarray(cost, dtype=np.float64), kind="stable"):
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += cost[i]
+    return owner
+
+
+def chain_shards(params, n, world, split_time=None, band_bounds=None, numT=None):
     """Candidate indices per rank when whole CHAINS are dealt out (``[shard_0, ..., shard_{world-1}]``).
 
     Candidates with identical parameter vectors share one lambda-correction chain, computed once per rank
     that holds any of them, and a chain costs its full latency however few members a rank has: interleaving a split x rate
     grid puts every chain on every rank - kernel 1 is then not sharded at all (BASELINE config 5: 2 048 chains x 32 members;
-    eight interleaved ranks each still run 2 048 chains).  Dealing chains keeps a chain on ONE rank, all its splits with it
-    (so ranks stay balanced): 256 chains per rank on eight GPUs - the one-chain-per-wave path.  Chains are dealt round-robin in
-    order of first appearance; without parameters (``params is None``: one chain) the split of ``shard_indices`` is used."""
+    eight interleaved ranks each still run 2 048 chains).  Dealing chains keeps a chain on ONE rank, all its splits with it:
+    256 chains per rank on eight GPUs - the one-chain-per-wave path.  Chains are dealt by COST, the longest first, each to the
+    rank with the least work so far (``chain_costs``, ``deal_lpt``; ``misti_multi_eval_batch`` deals its contexts the same way):
+    per-rank summed cost differs by less than one chain.  Without ``split_time`` all chains cost the same and the deal is
+    round-robin in order of first appearance; without parameters (``params is None``: one chain) the split of ``shard_indices``
+    is used."""
     if params is None or world == 1:
         return [shard_indices(n, r, world, interleave=True) for r in range(world)]
-    p = np.ascontiguousarray(np.asarray(params, dtype=np.float64).reshape(n, -1))
-    _, first, inverse = np.unique(p.view(np.dtype((np.void, p.dtype.itemsize * p.shape[1]))).ravel(), return_index=True, return_inverse=True)
-    rank_of_chain = np.empty(len(first), dtype=np.int64)
-    rank_of_chain[np.argsort(first, kind="stable")] = np.arange(len(first)) % world      # round-robin in order of first appearance
-    owner = rank_of_chain[inverse.ravel()]
+    chain, cost = chain_costs(params, n, split_time, band_bounds, numT)
+    owner = deal_lpt(cost, world)[chain]
     return [np.nonzero(owner == r)[0].astype(np.int64) for r in range(world)]
 
 
@@ -192,7 +231,7 @@ def search_sharded(search, starts, keys, group=None, device=None, **per_start):
         device = torch.device("cuda", torch.cuda.current_device())
     cols, widths = [], []
     for k in keys:                                     # one collective for all keys: a float64 table [block, sum of widths]
-        v = np.asarray(res[k], dtype=np.float64).reshape(b - a, -1)
+        v = np.asarray(res[k], dtype=np.float64).reshape(b - a, starts.shape[1] if k == "x" else 1)
         cols.append(v)
         widths.append(v.shape[1])
     table = torch.as_tensor(np.concatenate(cols, axis=1) if cols else np.zeros((b - a, 0)))
@@ -257,15 +296,22 @@ def evaluate_sharded(evaluate, split_time, params, jsfs, interleave=True, group=
     rank = dist.get_rank() if dist.is_initialized() else 0
     split_time = np.asarray(split_time, dtype=np.float64)
     n = split_time.shape[0]
-    shards = chain_shards(params, n, world) if by_chain else None      # whole chains per rank (see chain_shards)
+    shards = chain_shards(params, n, world, split_time) if by_chain else None      # whole chains per rank, dealt by cost (see chain_shards)
     idx = shards[rank] if by_chain else shard_indices(n, rank, world, interleave)
     p_loc = None if params is None else np.asarray(params, dtype=np.float64)[idx]
-    res = evaluate(split_time[idx], p_loc, jsfs)
-    llk = getattr(res, "llk", res)                       # a BatchResult
-    llk = torch.as_tensor(llk, dtype=torch.float64)
+    n_rep = 0 if jsfs is None else int(np.asarray(jsfs).reshape(-1, 8).shape[0])
+    if len(idx):
+        res = evaluate(split_time[idx], p_loc, jsfs)
+        llk = getattr(res, "llk", res)                   # a BatchResult
+        llk = torch.as_tensor(llk, dtype=torch.float64).reshape(len(idx), n_rep)
+        st = torch.as_tensor(np.asarray(res.status), dtype=torch.float64).reshape(len(idx), 1) if with_status else None
+    else:
+        # a rank without a candidate (more ranks than chains): it still takes part in the collective, with an empty block of
+        # the right width - reshape(0, -1) is ambiguous and the rank would die before the all_gather
+        llk = torch.empty((0, n_rep), dtype=torch.float64)
+        st = torch.empty((0, 1), dtype=torch.float64) if with_status else None
     if with_status:                                      # one collective: the status rides as an extra column
-        st = torch.as_tensor(np.asarray(res.status), dtype=torch.float64).reshape(-1, 1)
-        llk = torch.cat([llk.reshape(st.shape[0], -1), st], dim=1)
+        llk = torch.cat([llk, st], dim=1)
     if device is None and dist.is_initialized() and dist.get_backend(group) == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
     if device is not None:

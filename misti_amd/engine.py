@@ -368,6 +368,27 @@ class MultiEngine:
         _lib.check(self._lib.misti_multi_last_shards(self._m, a, b))
         return list(a), list(b)
 
+    def last_cost(self):
+        """Summed chain cost per context of the last ``evaluate`` (what the dealing balances: chain length + members / 64)."""
+        c = (C.c_double * len(self.devices))()
+        _lib.check(self._lib.misti_multi_last_cost(self._m, c))
+        return list(c)
+
+    def evaluate_dev_gathered(self, n_cand, rows_per_shard, d_split, d_params, n_rep, d_jsfs, d_llk_all, d_status_all=None, d_bounds=None):
+        """``misti_multi_eval_batch_dev``: context i evaluates ``n_cand[i]`` candidates from device pointers on ITS device and the
+        log-likelihoods are all-gathered on the devices by RCCL inside the library (every ``d_llk_all[i]`` ends as the whole
+        ``[D][rows_per_shard][n_rep]`` table).  Arguments are lists (one entry per context) of integer device addresses, e.g.
+        ``tensor.data_ptr()``.  Asynchronous; ``sync()`` waits for every context's stream."""
+        D = len(self.devices)
+        arr = lambda ptrs: (C.c_void_p * D)(*[C.c_void_p(int(p)) if p else None for p in ptrs])
+        n = (C.c_int64 * D)(*[int(v) for v in n_cand])
+        _lib.check(self._lib.misti_multi_eval_batch_dev(self._m, n, int(rows_per_shard), arr(d_split), arr(d_params) if d_params is not None else None,
+                                                        arr(d_bounds) if d_bounds is not None else None, int(n_rep), arr(d_jsfs), arr(d_llk_all),
+                                                        arr(d_status_all) if d_status_all is not None else None))
+
+    def sync(self):
+        _lib.check(self._lib.misti_multi_sync(self._m))
+
     def nm_solve(self, starts, split_time, jsfs_row, tol=1e-4, maxiter=1000):
         """``misti_multi_nm_solve``: ``Engine.nm_solve`` with the starts dealt to the devices in contiguous blocks."""
         st = _f64(starts, (-1, self.n_param))

@@ -188,6 +188,111 @@ def test_chain_shards_partition_and_balance():
     assert [len(s) for s in chain_shards(None, 10, 3)] == [4, 3, 3]
 
 
+def test_chains_are_dealt_by_cost_longest_first():
+    """Round 5: chains cost their LENGTH (largest split index of their members) + 1/64 per member, and are dealt
+    longest-processing-time-first - per-rank summed cost differs by less than one chain, where round-robin in order of first
+    appearance (round 4) left a rank with the long chains up to 40 % more work on a grid ordered by split."""
+    from misti_amd.dist import MEMBER_COST, chain_costs, chain_shards, deal_lpt
+    rng = np.random.default_rng(7)
+    n_chain = 61
+    rates = rng.random((n_chain, 2))
+    longest = rng.integers(20, 120, n_chain)                                       # every chain its own largest split
+    split, params = [], []
+    for c in range(n_chain):
+        m = int(rng.integers(1, 9))
+        st = np.sort(rng.integers(10, longest[c] + 1, m)).astype(float)
+        st[-1] = longest[c] if c % 5 else longest[c] - 0.5                         # some chains end on a fractional split
+        split += list(st)
+        params += [rates[c]] * m
+    order = rng.permutation(len(split))
+    split, params = np.array(split)[order], np.array(params)[order]
+    chain, cost = chain_costs(params, len(split), split)
+    assert len(cost) == n_chain
+    for c in range(n_chain):                                                       # cost = ceil(largest split) + members / 64
+        mine = chain == c
+        assert cost[c] == np.ceil(split[mine].max()) + MEMBER_COST * mine.sum()
+        assert len({tuple(q) for q in params[mine]}) == 1
+    for world in (2, 3, 4, 8):
+        sh = chain_shards(params, len(split), world, split)
+        assert np.array_equal(np.sort(np.concatenate(sh)), np.arange(len(split)))
+        load = np.array([cost[np.unique(chain[s])].sum() for s in sh])
+        for s in sh:                                                               # a chain never spans ranks
+            assert len(s) == sum((chain == c).sum() for c in np.unique(chain[s]))
+        assert load.max() - load.min() <= cost.max(), (world, load)                # "differs by at most one chain"
+        assert load.max() <= cost.sum() / world + cost.max()
+        rr = np.zeros(world)                                                       # round 4's deal of the same grid
+        for c in range(n_chain):
+            rr[c % world] += cost[c]
+        assert load.max() <= rr.max() + 1e-9
+    # equal costs: round-robin in order of first appearance, as before
+    assert list(deal_lpt(np.ones(7), 3)) == [0, 1, 2, 0, 1, 2, 0]
+    # band bounds are part of the chain key
+    bb = np.zeros((len(split), 1, 2), dtype=np.int32)
+    bb[::2, 0, 0] = 3
+    assert len(chain_costs(params, len(split), split, bb)[1]) > n_chain
+
+
+def _worker_status(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from misti_amd.dist import evaluate_sharded
+    split, params, jsfs = tiny_grid()[4:]
+    eng = OracleEngine()
+    llk, status = evaluate_sharded(eng.evaluate, split, params, jsfs, by_chain=True, with_status=True)
+    q.put((rank, llk.numpy(), status.numpy(), eng.chains_seen))
+    dist.destroy_process_group()
+
+
+def test_more_ranks_than_chains_with_status():
+    """`cli --gpus N` gathers [llk | status] with whole chains per rank; with more ranks than chains (3 chains,
+    4 ranks) one rank has no candidate - it used to die in `reshape(0, -1)` before the collective and take the sweep with it."""
+    world = 4
+    split, params, jsfs = tiny_grid()[4:]
+    want = OracleEngine().evaluate(split, params, jsfs)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_status, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(ch for _, _, _, ch in res if ch is not None) == [1, 1, 1] and sum(ch is None for _, _, _, ch in res) == 1
+    for rank, llk, status, _ in res:
+        assert np.array_equal(llk, want.llk) and np.array_equal(status, want.status) and status.dtype == np.int32, rank
+
+
+def _worker_few_starts(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from misti_amd.optimize import solve_batched_dev
+    starts, _ = _search_inputs()
+    x, llh, r = solve_batched_dev(StubSearchEngine(), 20.0, starts[:2], np.ones(8), tol=1e-6)
+    q.put((rank, x, llh, r["nfev"]))
+    dist.destroy_process_group()
+
+
+def test_fewer_starts_than_ranks():
+    """two starts over three ranks - the rank with an empty block takes part in the gather."""
+    world = 3
+    starts, _ = _search_inputs()
+    want = StubSearchEngine().nm_solve(starts[:2], 20.0, None, tol=1e-6)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_few_starts, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, x, llh, nfev in res:
+        assert np.array_equal(x, want["x"]) and np.array_equal(llh, want["llh"]) and np.array_equal(nfev, want["nfev"]), rank
+
+
 # ---- round 4: the product entry points that use more than one GPU, rehearsed over gloo -----------------------------------------
 def _cli_fixture(tmp_path):
     import json

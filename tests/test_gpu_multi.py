@@ -118,3 +118,85 @@ def test_multi_device_edge_shapes(grid):
         got = m.evaluate(w.split_time[sel], w.params[sel], w.jsfs)
         assert m.last_shards() == ([12, 0, 0], [1, 0, 0])
         assert np.array_equal(got.llk, one.llk, equal_nan=True)
+
+
+# ---- round 5: cost-aware dealing, the gather inside the library, no exception across the ABI -------------------------------------
+def test_chains_are_dealt_by_cost_and_results_do_not_change():
+    """Chains of very different length (a grid ordered by split: every rate has its own largest split): the contexts' summed chain
+    cost differs by less than one chain (longest-processing-time-first), the deal equals misti_amd.dist.chain_shards', and every
+    output is still bit for bit the single context's."""
+    from misti_amd import workloads
+    from misti_amd.dist import chain_costs, chain_shards
+    from misti_amd.engine import Engine, MultiEngine, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a), n_split=16, n_rate=9, first_split=40, max_rate=0.4)
+    rate_of = np.unique(w.params[:, 0], return_inverse=True)[1]
+    keep = w.split_time <= 43 + 1.5 * rate_of                                  # rate k keeps the splits up to 43 + 1.5 k
+    keep &= ~((rate_of == 3) & (w.split_time > 41))
+    split, params = w.split_time[keep].copy(), w.params[keep]
+    split[(rate_of[keep] == 5) & (split == split[rate_of[keep] == 5].max())] -= 0.5      # one chain ends on a fractional split
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        one = e.evaluate(split, params, w.jsfs, want_lc=True)
+    for D in (2, 3):
+        with MultiEngine(w.times, w.lh, devices=(0,) * D, **w.engine_kwargs()) as m:
+            got = m.evaluate(split, params, w.jsfs, want_lc=True)
+            cands, chains = m.last_shards()
+            cost = m.last_cost()
+        for k in ("llk", "jafs", "status", "lc"):
+            assert np.array_equal(getattr(got, k), getattr(one, k), equal_nan=True), (D, k)
+        chain, c = chain_costs(params, len(split), split)
+        assert sum(chains) == 9 and max(cost) - min(cost) <= c.max() and abs(sum(cost) - c.sum()) < 1e-9
+        sh = chain_shards(params, len(split), D, split)
+        assert [len(s) for s in sh] == cands
+        assert np.allclose(sorted(cost), sorted(c[np.unique(chain[s])].sum() for s in sh))
+
+
+def test_gather_inside_the_library_on_a_one_device_communicator():
+    """misti_multi_eval_batch_dev on the device list {0}: device pointers in, the log-likelihoods and statuses all-gathered by RCCL
+    (ncclAllGather on a communicator made by ncclCommInitAll) inside the library - the table a C caller gets without PCIe.  On one
+    device the gather is the identity, but the communicator, the grouped collective on the context's stream and the padding are real."""
+    import torch
+    from misti_amd import workloads
+    from misti_amd._lib import MistiError
+    from misti_amd.engine import Engine, MultiEngine, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a), n_split=6, n_rate=5, first_split=60, max_rate=0.5)
+    w.jsfs = np.vstack([w.jsfs, w.jsfs * 0.5])
+    n, R, per = w.n_cand, 2, w.n_cand + 3
+    dev = torch.device("cuda", 0)
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        one = e.evaluate(w.split_time, w.params, w.jsfs)
+    d_split = torch.as_tensor(w.split_time, device=dev)
+    d_par = torch.as_tensor(w.params, device=dev)
+    d_jsfs = torch.as_tensor(w.jsfs, device=dev)
+    d_all = torch.zeros((1, per, R), dtype=torch.float64, device=dev)
+    d_st = torch.zeros((1, per), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    with MultiEngine(w.times, w.lh, devices=(0,), **w.engine_kwargs()) as m:
+        for _ in range(2):                                                      # the communicator is made once and reused
+            m.evaluate_dev_gathered([n], per, [d_split.data_ptr()], [d_par.data_ptr()], R, [d_jsfs.data_ptr()], [d_all.data_ptr()], [d_st.data_ptr()])
+            m.sync()
+        got, st = d_all.cpu().numpy(), d_st.cpu().numpy()
+        assert np.array_equal(got[0, :n], one.llk, equal_nan=True) and np.isnan(got[0, n:]).all()
+        assert np.array_equal(st[0, :n], one.status) and (st[0, n:] == -1).all()
+        with pytest.raises(MistiError, match="do not fit"):
+            m.evaluate_dev_gathered([per + 1], per, [d_split.data_ptr()], [d_par.data_ptr()], R, [d_jsfs.data_ptr()], [d_all.data_ptr()])
+    with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m2:
+        with pytest.raises(MistiError, match="listed twice"):
+            m2.evaluate_dev_gathered([n, 0], per, [d_split.data_ptr()] * 2, [d_par.data_ptr()] * 2, R, [d_jsfs.data_ptr()] * 2, [d_all.data_ptr()] * 2)
+
+
+def test_an_exception_in_a_worker_thread_fails_the_call_not_the_process(grid, monkeypatch):
+    """include/misti_hip.h: no C++ exception crosses the ABI.  A worker thread that throws (test hook MISTI_MULTI_THROW_IN_WORKER,
+    read once in misti_create_multi) makes the call return MISTI_E_ARG with the context's message; the persistent workers survive
+    and the next call on another object still works."""
+    from misti_amd._lib import MistiError
+    from misti_amd.engine import MultiEngine
+    w = grid
+    monkeypatch.setenv("MISTI_MULTI_THROW_IN_WORKER", "1")
+    with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m:
+        for _ in range(2):
+            with pytest.raises(MistiError, match=r"context 1 of 2.*MISTI_MULTI_THROW_IN_WORKER") as ei:
+                m.evaluate(w.split_time, w.params, w.jsfs)
+            assert ei.value.code == -1
+    monkeypatch.delenv("MISTI_MULTI_THROW_IN_WORKER")
+    with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m:
+        assert np.isfinite(m.evaluate(w.split_time, w.params, w.jsfs).llk).any()

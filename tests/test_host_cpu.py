@@ -100,8 +100,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.misti_abi_version() == 4 == _lib.ABI_VERSION
-    assert "#define MISTI_ABI_VERSION 4" in hdr
+    assert lib.misti_abi_version() == 5 == _lib.ABI_VERSION
+    assert "#define MISTI_ABI_VERSION 5" in hdr
 
 
 def test_tables_match_oracle_structure():
@@ -225,3 +225,11 @@ def test_read_migration_against_the_reference_reader(tmp_path):
             assert d.migStart is None and d.migEnd is None and d.mi is None
         # round trip: the writer's own text of the same model reads back to the same numbers
         assert len(d.pr) == len(d.times) and any(any(v != 0 for v in row) for row in d.pr)
+
+
+def test_cli_rejects_gpus_together_with_devices(capsys):
+    """`--gpus N` (one rank per GPU) and `--devices` (a device list in one process) exclude each other - N ranks that each
+    opened the whole list would run N x D contexts; the command refuses before reading any file."""
+    from misti_amd import cli
+    rc = cli.main(["a.psmc", "b.psmc", "d.sfs", "20", "--grid-st", "18", "20", "--gpus", "2", "--devices", "0,1"])
+    assert rc == 2 and "exclude each other" in capsys.readouterr().err
