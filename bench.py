@@ -498,6 +498,53 @@ def main():
                 lane.close()
         return res
 
+    def llk_roofline_leg(n_cand=65536, n_rep=1000, reps=20):
+        """The replicate epilogue alone (the one HBM-write-bound kernel of the path, MigrationInference.py:600-609) at a size
+        where the roofline means something: `misti_llk_dev` on n_cand spectra x n_rep bootstrap replicates - 8 bytes written per value
+        (524 MB at the default), 56 in per candidate, 72 in per replicate.  Duration: HIP events on the launch stream around the
+        kernel (misti_kernel_times[2]).  Also at BASELINE config 4's own size (256 x 1 000), where the launch dominates."""
+        rng = np.random.default_rng(11)
+        out_legs = {}
+        w4 = build_workload("config4", spec)
+        with Engine(w4.times, w4.lh, device=local_rank, **w4.engine_kwargs()) as eng:
+            rows = np.ascontiguousarray(np.resize(w4.jsfs, (n_rep, 8)), dtype=np.float64)
+            d_rows = torch.as_tensor(rows, device=dev)
+            for tag, nc in (("large", n_cand), ("config4", 256)):
+                jf = rng.random((nc, 7)) + 0.05
+                jf /= jf.sum(axis=1, keepdims=True)
+                d_jafs = torch.as_tensor(jf, device=dev)
+                d_llk = torch.empty((nc, n_rep), dtype=torch.float64, device=dev)
+                torch.cuda.synchronize()
+                for _ in range(3):
+                    eng.llk_dev(nc, d_jafs.data_ptr(), 0, n_rep, d_rows.data_ptr(), d_llk.data_ptr())
+                eng.sync()
+                eng.enable_timing(True)
+                eng.kernel_times(reset=True)
+                for _ in range(reps):
+                    eng.llk_dev(nc, d_jafs.data_ptr(), 0, n_rep, d_rows.data_ptr(), d_llk.data_ptr())
+                eng.sync()
+                kms, kn = eng.kernel_times(reset=True)
+                eng.enable_timing(False)
+                ms = kms["llk"] / max(1, kn["llk"])
+                nbytes = 8.0 * nc * n_rep + 56.0 * nc + 72.0 * n_rep
+                # the values themselves, against NumPy on a sample of rows (the parity tests hold the kernel to the bits of the inline epilogue)
+                got = d_llk[:: max(1, nc // 16)].cpu().numpy()
+                lj = np.log(np.stack([jf[:, 0] + jf[:, 6], jf[:, 1] + jf[:, 5], jf[:, 2] + jf[:, 4], jf[:, 3]], axis=1))[:: max(1, nc // 16)]
+                ff = np.stack([rows[:, 1] + rows[:, 7], rows[:, 2] + rows[:, 6], rows[:, 3] + rows[:, 5], rows[:, 4]], axis=1)
+                from scipy.special import gammaln
+                cst = gammaln(rows[:, 1:].sum(axis=1) + 1) - gammaln(ff + 1).sum(axis=1)
+                want = cst[None, :] + lj @ ff.T
+                out_legs[tag] = {"kernel": "misti::llk_kernel", "spectra": nc, "replicates": n_rep, "ms_per_launch": ms, "launches": int(kn["llk"]),
+                                 "algorithmic_bytes_per_launch": nbytes, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_of_achievable_6300": nbytes / (ms * 1e-3) / 1e9 / 6300.0,
+                                 "llk_per_s": nc * n_rep / (ms * 1e-3), "max_rel_err_vs_numpy": float(np.max(np.abs(got / want - 1.0))),
+                                 "traffic": None}
+                del d_llk, d_jafs
+        out_legs["note"] = ("the replicate epilogue alone (misti_llk_dev): algorithmic bytes = 8 per value + 56 per spectrum + 72 per replicate; duration = HIP events "
+                            "around the kernel on its stream; peak 8 TB/s (6.3 TB/s is what a plain float4 copy reaches on this chip: MI355X_MICROARCH.md); "
+                            "`traffic`: WRITE_SIZE / FETCH_SIZE of the same launch, profiles/rNN_pmc_llk.json")
+        return out_legs
+
     def host_abi_leg(workload, k):
         """The C ABI's HOST-buffer form, misti_eval_batch (pageable NumPy arrays in and out, as a ctypes caller of the reference
         would hold them; PCIe both ways inside the call, which returns when the results are in the caller's memory): K calls
@@ -583,7 +630,7 @@ def main():
         "metric": metric,
         "value": value, "unit": "llk evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "library": {"build_id": _build_id(), "abi": 5},
         "config": {"workload": w.name, "candidates_per_gpu": n, "candidates_total": job_cands, "replicates": R, "numT": w.numT,
                    "batches_in_flight": n_streams, "streams": n_streams,
                    "world_size": group_world, "candidates_per_rank": main_leg["cands_per_rank"], "chains_per_rank": main_leg["chains_per_rank"],
@@ -673,6 +720,11 @@ def main():
                 extra["host_abi"] = host_abi_leg("config2", max(16, min(a.steps, 128)))
             except Exception as e:                 # noqa: BLE001
                 extra["host_abi"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and a.workload in ("config2", "config4"):
+            try:
+                extra["llk_kernel"] = llk_roofline_leg()
+            except Exception as e:                 # noqa: BLE001
+                extra["llk_kernel"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if watchdog is not None:
         fence()                                    # every rank is through its secondary legs
@@ -691,6 +743,8 @@ def main():
         ab = algorithmic_bytes(w, R, mine)
         achieved = ab[dom] / (per_ms[dom] * 1e-3) / 1e9 if per_ms[dom] > 0 else 0.0
         out["roofline"] = roofline_block(a.workload, world, dom, per_ms, ab, achieved, n)
+        if "llk_kernel" in out:
+            out["roofline"]["llk_kernel"] = out.pop("llk_kernel")       # the HBM-write-bound kernel reported separately
         v = out["roofline"].get("valu")
         if v and v.get("wave_insts"):
             # the same counters at the rate of the headline leg: launches of the dominant kernel per second x its wave-instructions x 4 cycles,
@@ -763,6 +817,11 @@ def main():
     return 0
 
 
+def _build_id():
+    from misti_amd import _lib as _mlib
+    return _mlib.build_id()
+
+
 def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
     """`roofline` of the dominant kernel.
 
@@ -777,6 +836,13 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
         try:
             j = json.load(open(pmc))
             j = j.get("workloads", {}).get(workload) or (j if j.get("workload") == workload else None)
+            if j:
+                from misti_amd import _lib as _mlib
+                stored_id, mine_id = j.get("build_id"), _mlib.build_id()
+                if stored_id != mine_id:
+                    # counters of ANOTHER build say nothing about the library that ran: no traffic, no VALU fraction
+                    traffic_source = "stale: profiles/pmc_latest.json holds counters of build %s, the loaded library is build %s" % (stored_id, mine_id)
+                    j = None
             if j:
                 traffic = j.get(dom + "_hbm_bytes_per_launch")
                 traffic_source = "stored: profiles/pmc_latest.json <- " + str(j.get("source")) + " (not measured in this run)"
@@ -837,7 +903,7 @@ def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
                        "the resource that binds"}
     else:
         blk = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-               "note": "no stored SQ counters for this workload: HBM figures only; the path is bound by fp64 VALU issue latency, not by HBM (SURVEY 8d)"}
+               "note": "no stored SQ counters of this build for this workload: HBM figures only; the path is bound by fp64 VALU issue latency, not by HBM (SURVEY 8d)"}
     blk.update(common)
     if second:
         blk["second_kernel"] = second

@@ -109,6 +109,9 @@ typedef struct misti_ctx misti_ctx;
 
 /* ---- library ------------------------------------------------------------- */
 int         misti_abi_version(void);
+/* Hash of the sources and switches this library was built from (misti_amd/build.py: source_hash): measurements stored beside the
+ * code (profiles/pmc_latest.json) name the build they were taken on, and bench.py prices a run only with counters of ITS build. */
+const char* misti_build_id(void);
 const char* misti_last_error(void);
 int         misti_device_count(void);            /* HIP devices visible; <0 on error */
 

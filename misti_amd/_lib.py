@@ -51,6 +51,7 @@ _PD, _PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
 SYMBOLS = {
     "misti_abi_version": (C.c_int, []),
     "misti_last_error": (C.c_char_p, []),
+    "misti_build_id": (C.c_char_p, []),
     "misti_device_count": (C.c_int, []),
     "misti_create": (C.c_int, [C.POINTER(Model), C.c_int, C.POINTER(C.c_void_p)]),
     "misti_destroy": (C.c_int, [C.c_void_p]),
@@ -146,6 +147,11 @@ def load(build_if_missing=True):
                          % (path, lib.misti_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def build_id():
+    """The loaded library's own record of the sources it was built from (``misti_build_id``)."""
+    return load().misti_build_id().decode()
 
 
 def check(code):

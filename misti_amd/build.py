@@ -56,9 +56,22 @@ def build(force=False, verbose=False, extra=(), out=None):
         lock.close()
 
 
+def source_hash(extra=()):
+    """sha256 (16 hex digits) over the sources, the headers and the switches a build was made with: the library carries it
+    (`misti_build_id()`), stored rocprofv3 counters carry it (profiles/pmc_latest.json), and bench.py refuses to price a run
+    with counters of another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read() + b"\0")
+    h.update(" ".join(list(extra) + [os.environ.get("MISTI_FP_CONTRACT", "on"), os.environ.get("MISTI_STAMP", ""), os.environ.get("MISTI_STAMP2", "")]).encode())
+    return h.hexdigest()[:16]
+
+
 def _build_locked(target, verbose, extra):
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-           "-Wall", "-Wno-unused-function"]
+           "-Wall", "-Wno-unused-function", '-DMISTI_BUILD_ID="%s"' % source_hash(extra)]
     # Contraction within a source expression only (clang's `on`), not `fast`: with `fast` the backend fuses a multiply
     # and an add wherever its DAG happens to bring them together, which depends on inlining context - two template
     # instantiations of the same source could then round differently, and a chain's bits would depend on how many

@@ -108,6 +108,8 @@ struct misti_ctx {
     hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
     hipEvent_t last_ev = nullptr;       // recorded behind every batch: lets OTHER contexts see whether this one has work in flight
     bool last_ev_set = false;
+    hipStream_t side_stream = nullptr;  // phase 1 of a two-phase batch (run_dev): what follows the chains a packed launch completed, beside its resume launch
+    hipEvent_t packed_ev = nullptr, side_ev = nullptr;
     DevBuf nm_f64, nm_i32;              // batched Nelder-Mead: simplices, points, counters (misti_nm_solve)
     int32_t* nm_live_host = nullptr;    // pinned: live starts after the last two finished iterations
     int64_t nm_iterations = 0;          // iterations issued by the last misti_nm_solve
@@ -417,7 +419,18 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         const int busy_from = c->tune.busy_contexts >= 0 ? c->tune.busy_contexts : misti::FOLLOW_BUSY_CONTEXTS;
         if (yield_nfev > 0 && busy_from > 0 && busy() >= busy_from) yield_nfev = 0;
     }
-    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, yield_nfev, c->stream), a, b);
+    // Two phases behind a packed launch that lets chains yield (--cpfit; misti_kernels.hip: wrong_phase): what waits for the chains that launch
+    // completed - trunks, tails, the candidate kernel of their members: 91 % of BASELINE config 3 - runs on a second stream BESIDE the resume
+    // launch, which is one chain latency long and leaves most of the chip idle; the members of the chains that yielded follow behind it on the
+    // batch's own stream, which then waits for the second one.  MISTI_TWO_PHASE=0 keeps everything on one stream.
+    const bool two_phase = yield_nfev > 0 && (c->dm.flags & MISTI_CPFIT) && c->tune.two_phase;
+    if (two_phase) {
+        if (!c->side_stream) HIP_TRY_EV(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), a, b);
+        if (!c->packed_ev) HIP_TRY_EV(hipEventCreateWithFlags(&c->packed_ev, hipEventDisableTiming), a, b);
+        if (!c->side_ev) HIP_TRY_EV(hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming), a, b);
+    }
+    HIP_TRY_EV(misti::launch_correct(c->dm, n_cand, cb, d_split, d_params, cpw_chains, follow, est_chains, c->tune, yield_nfev, c->stream,
+                                     two_phase ? c->packed_ev : nullptr), a, b);
     // Kernel 2 in single-wave workgroups (they slip into any free wave slot while other batches' chain kernels are resident: +21 % on
     // the headline grid with 20 batches in flight) - except behind a chip-filling one-chain-per-wave launch of this context's own:
     // there the next such launch was measured 18 % slower after single-wave workgroups (1.66 -> 1.96 ms on 1 024 chains; the placement
@@ -429,9 +442,16 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     HIP_TRY(c->ws_diag.reserve(nc * sizeof(double)));
     c->diag_n = n_cand;
     if (int r = record_begin(c, 1, &a, &b)) return r;
+    const bool skip_post = (hints & RUN_INTEGER_SPLITS) && (follow || ntr == 0);
+    if (two_phase) {
+        HIP_TRY_EV(hipStreamWaitEvent(c->side_stream, c->packed_ev, 0), a, b);
+        HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
+                                          n_rep, d_jsfs, d_consts, d_llk, follow, skip_post, single_waves, c->tune, c->side_stream, 1), a, b);
+        HIP_TRY_EV(hipEventRecord(c->side_ev, c->side_stream), a, b);
+    }
     HIP_TRY_EV(misti::launch_spectrum(c->dm, n_cand, d_order, d_split, d_params, cb, d_lc, d_pr, d_jafs, d_status, c->ws_diag.as<double>(),
-                                      n_rep, d_jsfs, d_consts, d_llk, follow, (hints & RUN_INTEGER_SPLITS) && (follow || ntr == 0), single_waves,
-                                      c->tune, c->stream), a, b);
+                                      n_rep, d_jsfs, d_consts, d_llk, follow, skip_post, single_waves, c->tune, c->stream, two_phase ? 2 : 0), a, b);
+    if (two_phase) HIP_TRY_EV(hipStreamWaitEvent(c->stream, c->side_ev, 0), a, b);            // the batch's stream is behind both phases from here on
     if (int r = record_end(c, 1, a, b)) return r;
     if (c->timing) c->launches[1] += 1;
     if (n_rep > 0 && !llk_inline) {
@@ -453,6 +473,10 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
 extern "C" {
 
 int misti_abi_version(void) { return MISTI_ABI_VERSION; }
+#ifndef MISTI_BUILD_ID
+#define MISTI_BUILD_ID "unknown"
+#endif
+const char* misti_build_id(void) { return MISTI_BUILD_ID; }
 
 const char* misti_last_error(void) { return g_err.c_str(); }
 
@@ -634,6 +658,9 @@ int misti_destroy(misti_ctx* c) {
         for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->hint_host) (void)hipHostFree(c->hint_host);
+    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
+    if (c->packed_ev) (void)hipEventDestroy(c->packed_ev);
+    if (c->side_ev) (void)hipEventDestroy(c->side_ev);
     delete c;
     return 0;
 }

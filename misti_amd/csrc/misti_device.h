@@ -192,6 +192,7 @@ struct Tuning {
     int min_blocks = 0;        // MISTI_FOLLOW_MIN_BLOCKS: least workgroups of that launch (0: FOLLOW_MIN_BLOCKS)
     int yield_nfev = -1;       // MISTI_YIELD_NFEV: evaluations after which a solve of a PACKED launch yields its chain to correct_resume_kernel
                                // (-1: YIELD_NFEV; 0: never)
+    bool two_phase = true;     // MISTI_TWO_PHASE=0: everything behind a yielding packed launch on one stream (no phase-1 launch beside the resume launch)
     bool pairing = true;       // MISTI_FOLLOW_PAIRING=0: the chain always on the first wave of its workgroup (default: placement-aware, correct_follow_kernel)
     int k2_single_waves = -1;  // MISTI_K2_SINGLE_WAVES: 1 / 0 forces kernel 2's workgroups to one / four waves (-1: chosen per batch, run_dev)
     int busy_contexts = -1;    // MISTI_FOLLOW_BUSY_CONTEXTS: other contexts with a batch in flight from which on a batch of more than
@@ -205,10 +206,11 @@ hipError_t launch_setup(const DevModel& m, int64_t n, const double* params, cons
 int correct_cands_per_wave(int64_t n_items, const Tuning& tn);
 bool trunk_follows(int cpw_chains, int64_t trunk_cap, const Tuning& tn);
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream);
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream, hipEvent_t after_packed = nullptr);
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
-                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, bool single_waves, const Tuning& tn, hipStream_t stream);
+                           int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, bool single_waves, const Tuning& tn, hipStream_t stream,
+                           int phase = 0);
 hipError_t launch_forward(const DevModel& m, int64_t n_cand, const double* split, const double* params, int hold_mu, double* lh_out, double* pr_out,
                           int32_t* status, hipStream_t stream);
 hipError_t launch_argmax(int64_t n_cand, int64_t n_rep, const double* llk, int32_t* best, double* best_llk, hipStream_t stream);

@@ -229,6 +229,30 @@ __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double 
     if (INT) { vint[0] = b0; vint[1] = b1; vint[2] = b2; }
 }
 
+// Reciprocal / square root for the solver's bookkeeping: hardware seed + Newton steps, ~1 ulp,
+// a third of the instructions of the correctly rounded forms (no denormal/overflow scaling:
+// every operand here is a normal-range quantity or the result is tested for finiteness anyway).
+__device__ __forceinline__ double rcp64(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double sqrt64(double x) {
+    // straight-line: the solver's bookkeeping is one dependent instruction stream, every branch costs it a handful of
+    // scalar instructions.  rsq(0) = inf and rsq(inf) = 0 make the Newton steps NaN: those two inputs are passed through;
+    // negative and NaN inputs give NaN by themselves (rsq), as sqrt() does.
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    const double s = fma(d, h, g);
+    return (x == 0.0 || x == INFINITY) ? x : s;
+}
+
 // Structural reduction of the pair chain.  With migration in one direction only (mu1 == 0: nothing enters "both in
 // population 0") and that state empty in both genomes - it is, exactly, from the first interval in which its rate ran
 // away: exp(-rate x length) underflows or falls below PAIR_EMPTY of the total - the three-state chain is the two-state one on (both in population 1, one in each), whose
@@ -287,6 +311,113 @@ __device__ __forceinline__ void pair_cascade(int which, double l0, double l1, do
     v[2] = w2;
 }
 
+// exp(M) v for migration in BOTH directions, in closed form (round 5; until then the stiff two-way generator went through a dense
+// degree-12 Taylor kernel and up to 17 squarings: ~2 000 instructions per evaluation, a systematic relative error of ~1e-11 at
+// |M| = 1e5, and the floor of every packed launch - the resumed chains of BASELINE configs 3 and 5 spend their time there).
+// In the order (both in 0, one in each, both in 1) the generator is tridiagonal with positive off-diagonal products, hence similar to
+// the symmetric  [[-d0, s, 0], [s, -d2, s], [0, s, -d1]],  s^2 = 2 mu0 mu1:  three real eigenvalues -x_i, the roots of the secular
+// equation   (d2 - x) = s^2 / (d0 - x) + s^2 / (d1 - x),   one below both poles d0, d1, one between them, one above, and
+//     exp(M) v = sum_i e^{-x_i} r_i (l_i . v) / (l_i . r_i),     r_i = (mu1 / g0, mu0 / g1, 1),  l_i = (2 mu0 / g0, 2 mu1 / g1, 1),
+//     g0 = d0 - x_i,  g1 = d1 - x_i,   l_i . r_i = 1 + s^2 / g0^2 + s^2 / g1^2
+// (rows / columns 0 and 1 of (M + x) r = 0; no square root, no matrix product).  What decides the accuracy is the GAPS g0, g1, so
+// every root is found in the variable "distance to the nearest pole" (as LAPACK's dlaed4 does for its secular equation): for the
+// outer roots  F(t) = c + t - s^2/t - s^2/(G + t),  for the middle one  F(t) = c + t - s^2/t + s^2/(G - t)  on (0, G/2]
+// (G = |d0 - d1|; c = the distance of d2 from that pole, signed) - increasing and concave, so Newton's iteration from a point left of the
+// root converges monotonically, without safeguards, and two such points come from quadratics (a function above F with a computable
+// root: the far pole dropped, or the near pole moved to the far one).  The smallest root when d2 lies below both poles is found as
+// d2 - e instead (K(e) = e - s^2/(A0 + e) - s^2/(A1 + e), A = d - d2 > 0): the runaway rates make the poles huge and the root stays at
+// d2, where a distance to a pole of 1e5 would lose eleven digits of e^{-x}.  Newton's iteration reaches rounding from the better of the two
+// starts in 1 - 3 steps per root over 6 000 random generators spanning rates 1e-2 ... 3e5 and migration 1e-6 ... 3 (scratch prototype against 60-digit
+// arithmetic: 7e-16 of the norm of the result in the stiff regime; the eigenvector scaling costs a factor sqrt(mu1 / mu0) where the two
+// migration rates differ by orders of magnitude).  Smooth in the varied rate to a few ulps, like pair_cascade.
+__device__ __forceinline__ double pe_qroot(double a, double c, double s2) {          // positive root of a t^2 + c t - s2 = 0
+    const double r = sqrt64(c * c + 4.0 * a * s2);
+    return c >= 0.0 ? 2.0 * s2 * rcp64(c + r) : (r - c) * rcp64(2.0 * a);
+}
+// Newton's steps stop for the whole wave once every lane's last correction is below PE_TOL of its root: the iteration converges
+// quadratically from the left, so the correction after that one is below rounding (prototype: 1e-14 of the result's norm at worst,
+// 4.4 Newton steps per evaluation for all three roots together where a fixed count needs 18).
+constexpr int PE_NEWTON_MAX = 12;
+constexpr double PE_TOL = 1e-9;
+__device__ __forceinline__ double pe_outer(double c, double G, double s2) {
+    // left starts: the far pole dropped (c + t - s2/t), or the near pole moved onto the far one (c + t - 2 s2/(G + t): t^2 + (c + G) t = 2 s2 - c G)
+    const double cg = c + G, r = sqrt64((c - G) * (c - G) + 8.0 * s2);
+    const double t2 = cg >= 0.0 ? 2.0 * (2.0 * s2 - c * G) * rcp64(cg + r) : 0.5 * (r - cg);
+    double t = fmax(pe_qroot(1.0, c, s2), t2);
+    bool done = false;                    // a lane's root is frozen by ITS OWN test: what else sits in the wave changes no bit of it
+    for (int it = 0; it < PE_NEWTON_MAX; ++it) {
+        const double a = rcp64(t), b = rcp64(G + t);
+        const double F = ((c + t) - s2 * a) - s2 * b, dF = 1.0 + s2 * (a * a + b * b);
+        const double d = F * rcp64(dF);
+        t = done ? t : t - d;
+        done = done || !(fabs(d) > PE_TOL * t);
+        if (!__any(!done)) break;
+    }
+    return t;
+}
+__device__ __forceinline__ double pe_middle(double c, double G, double s2) {
+    const double iG = rcp64(G);
+    double t = fmax(pe_qroot(1.0, c + 2.0 * s2 * iG, s2), pe_qroot(1.0 + 2.0 * s2 * iG * iG, c + s2 * iG, s2));
+    bool done = false;
+    for (int it = 0; it < PE_NEWTON_MAX; ++it) {
+        const double a = rcp64(t), b = rcp64(G - t);
+        const double F = ((c + t) - s2 * a) + s2 * b, dF = 1.0 + s2 * (a * a + b * b);
+        const double d = F * rcp64(dF);
+        t = done ? t : t - d;
+        done = done || !(fabs(d) > PE_TOL * t);
+        if (!__any(!done)) break;
+    }
+    return t;
+}
+__device__ __forceinline__ double pe_below(double A0, double A1, double s2) {
+    double e = fmax(pe_qroot(1.0, fmin(A0, A1), s2), pe_qroot(1.0, fmax(A0, A1), 2.0 * s2));
+    bool done = false;
+    for (int it = 0; it < PE_NEWTON_MAX; ++it) {
+        const double a = rcp64(A0 + e), b = rcp64(A1 + e);
+        const double K = (e - s2 * a) - s2 * b, dK = 1.0 + s2 * (a * a + b * b);
+        const double d = K * rcp64(dK);
+        e = done ? e : e - d;
+        done = done || !(fabs(d) > PE_TOL * e);
+        if (!__any(!done)) break;
+    }
+    return e;
+}
+__device__ __forceinline__ void pair_eigen(double l0, double l1, double mu0, double mu1, double v[3]) {
+    const double d0 = 2.0 * mu0 + l0, d1 = 2.0 * mu1 + l1, d2 = mu0 + mu1, s2 = 2.0 * mu0 * mu1;
+    const bool low0 = d0 <= d1;                          // which pole is the lower one
+    const double p = low0 ? d0 : d1, P = low0 ? d1 : d0, G = P - p;
+    // per root: x and the gaps (p - x, P - x)
+    double x[3], gp[3], gP[3];
+    if (d2 < p) { const double e = pe_below(p - d2, P - d2, s2); x[0] = d2 - e; gp[0] = (p - d2) + e; gP[0] = (P - d2) + e; }
+    else { const double t = pe_outer(d2 - p, G, s2); x[0] = p - t; gp[0] = t; gP[0] = G + t; }
+    const bool hi = d2 > p + 0.5 * G;                    // the middle root lies in the half of (p, P) on d2's side of the midpoint
+    {
+        const double t = G > 0.0 ? pe_middle(hi ? d2 - P : p - d2, G, s2) : 0.0;
+        x[1] = hi ? P - t : p + t; gp[1] = hi ? -(G - t) : -t; gP[1] = hi ? t : G - t;
+    }
+    // the largest root lies above the upper pole: with a runaway rate its e^{-x} is zero beside the smallest root's - not computed then
+    // (a per-lane decision: lanes that need it compute it, and a lane's result never depends on its company in the wave)
+    const bool third = P - x[0] <= 745.0;
+    x[2] = 0.0; gp[2] = -1.0; gP[2] = -1.0;        // placeholders of a lane without a third term (its weight below is an exact zero)
+    if (third) { const double t = pe_outer(P - d2, G, s2); x[2] = P + t; gp[2] = -(G + t); gP[2] = -t; }
+    double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i == 2 && !__any(third)) break;
+        const double ex = (i == 2 && !third) ? 0.0 : exp(-x[i]);
+        const double i0 = rcp64(low0 ? gp[i] : gP[i]), i1 = rcp64(low0 ? gP[i] : gp[i]);        // 1 / (d0 - x), 1 / (d1 - x)
+        double cf = (((2.0 * mu0) * v[0]) * i0 + ((2.0 * mu1) * v[1]) * i1 + v[2]) * rcp64(1.0 + s2 * (i0 * i0 + i1 * i1));
+        double r0 = mu1 * i0, r1 = mu0 * i1, r2 = 1.0;
+        if (i == 1 && !(G > 0.0)) {
+            // coinciding poles: the middle eigenvalue IS the pole, right vector (mu1, -mu0, 0), left (mu0, -mu1, 0), l . r = s^2
+            cf = (mu0 * v[0] - mu1 * v[1]) * rcp64(s2); r0 = mu1; r1 = -mu0; r2 = 0.0;
+        }
+        const double z = ex * cf;
+        w0 = fma(z, r0, w0); w1 = fma(z, r1, w1); w2 = fma(z, r2, w2);
+    }
+    v[0] = w0; v[1] = w1; v[2] = w2;
+}
+
 // q, neg: the SAME for every lane of the candidate's group (computed by the caller from the
 // base point and both forward-difference points).  M = N - q I with N >= 0.  When a state is
 // numerically decoupled (e.g. no mass and no inflow in "both in pop 0" after a runaway rate
@@ -330,6 +461,15 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
             if (!ok) { v[0] = v[1] = v[2] = NAN; }
             return;
         }
+#ifndef MISTI_PAIR_EIGEN
+#define MISTI_PAIR_EIGEN 1
+#endif
+#if MISTI_PAIR_EIGEN
+        // migration in both directions: the closed form over the three eigenvalues of the (symmetrisable) generator (pair_eigen)
+        pair_eigen(l0, l1, mu0, mu1, v);
+        if (!ok) { v[0] = v[1] = v[2] = NAN; }
+        return;
+#endif
         double B[3][3] = {{-d0 * scl, 0.0, mu1 * scl}, {0.0, -d1 * scl, mu0 * scl}, {2.0 * mu0 * scl, 2.0 * mu1 * scl, -d2 * scl}};
         // Horner, E = I + B E / k for k = 12 .. 1.  The first step (E = I) is B / 12 + I; B[0][1] = B[1][0] = 0 are left out
         // of the products - with the fused forms spelt out both give the bits of the full 3x3 product for finite entries.
@@ -452,30 +592,6 @@ __device__ __forceinline__ void solve3_ge(const double Min[3][3], const double b
     x[2] = r[2] / A[2][2];
     x[1] = (r[1] - A[1][2] * x[2]) / A[1][1];
     x[0] = ((r[0] - A[0][1] * x[1]) - A[0][2] * x[2]) / A[0][0];
-}
-
-// Reciprocal / square root for the solver's bookkeeping: hardware seed + Newton steps, ~1 ulp,
-// a third of the instructions of the correctly rounded forms (no denormal/overflow scaling:
-// every operand here is a normal-range quantity or the result is tested for finiteness anyway).
-__device__ __forceinline__ double rcp64(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ double sqrt64(double x) {
-    // straight-line: the solver's bookkeeping is one dependent instruction stream, every branch costs it a handful of
-    // scalar instructions.  rsq(0) = inf and rsq(inf) = 0 make the Newton steps NaN: those two inputs are passed through;
-    // negative and NaN inputs give NaN by themselves (rsq), as sqrt() does.
-    double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g); h = fma(h, r, h);
-    double d = fma(-g, g, x);
-    const double s = fma(d, h, g);
-    return (x == 0.0 || x == INFINITY) ? x : s;
 }
 
 // ---- the REFERENCE's form of the default fit's expected coalescence time, imitated operation by operation ----
@@ -1137,6 +1253,7 @@ __device__ __forceinline__ bool ect_noise_continues(const PairProblem& pb, doubl
 // MigrationInference.CorrectLambdas, loop t < splitT (:311-354).  All values are
 // wave-uniform except inside pair_eval.  Returns false on "correction failed".
 struct PairState { double p[2][3]; };
+__device__ __forceinline__ bool wrong_phase(const ChainBufs& cb, int64_t ch, int phase);
 
 template <int GROUP = 1>
 __device__ __forceinline__ void pulse_pairs(PairState& ps, double pu0, double pu1) {
@@ -1293,7 +1410,7 @@ template <bool CPFIT, int GROUP, bool TAIL, bool PRE = false>
 __device__ __forceinline__
 void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* __restrict__ split_time, const double* __restrict__ params,
                   int64_t block, double* lds, double* lc_sh = nullptr, volatile int* flags = nullptr, double* pre = nullptr,
-                  const int32_t* chain_map = nullptr, int yield_nfev = 0, int t_start = 0) {
+                  const int32_t* chain_map = nullptr, int yield_nfev = 0, int t_start = 0, int phase = 0) {
     const int lane = lane_id();
     const int sub = lane % GROUP;
     const int64_t n_live = TAIL ? n_items : (int64_t)cb.n_chains[0];
@@ -1354,6 +1471,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
         if (status != MISTI_OK || G.ins < 0) return;               // nothing to do: no fractional split
         if (cb.tail_solver) sv_w = cb.tail_solver + cand - G.ins;
         const int64_t ch = chain_of(cb, cand);
+        if (wrong_phase(cb, ch, phase)) return;                    // this chain's members belong to the other phase's launch
         if (cb.fail_t[ch] < G.ins) return;                         // the chain failed before this candidate's tail
         t = G.ins;
         const double* r = cb.trace + (ch * (int64_t)(m.numT + 1) + t) * 6;
@@ -1787,6 +1905,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 cb.resume_t[slot] = t;
                 cb.resume_list[atomicAdd(&cb.n_chains[3], 1)] = (int32_t)slot;
             } else {
+                if (yield_nfev > 0) cb.resume_t[slot] = -1;               // a packed launch that lets chains yield: this one is complete (see chain_phase)
                 cb.fail_t[slot] = (status == MISTI_OK) ? 0x7fffffff : t;   // t = the interval that failed
                 cb.fail_status[slot] = status;
             }
@@ -1834,6 +1953,9 @@ void correct_resume_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
     __shared__ int next;
     const int n_res = cb.n_chains[3];
     if ((int)blockIdx.x >= n_res) return;
+    // the launch waits for its longest chain, and the phase-1 candidate waves of the same batch run beside it (launch_spectrum): the
+    // chains get the issue priority on the SIMDs they share
+    __builtin_amdgcn_s_setprio(3);
     double* pre = lds + 3 * (size_t)m.numT;
     for (;;) {
         if (threadIdx.x == 0) next = atomicAdd(&cb.n_chains[2], 1);
@@ -1845,6 +1967,14 @@ void correct_resume_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
         correct_body<CPFIT, 64, false, true>(m, n_items, cb, split_time, params, ch, lds, nullptr, nullptr, pre, nullptr, 0, cb.resume_t[ch]);
         __syncthreads();
     }
+}
+
+// A packed launch whose long chains YIELD to the resume launch finishes most chains itself (BASELINE config 3: 91 %).  What waits for a
+// chain - its trunk, the tails and the candidate kernel of its members - therefore runs in two PHASES: phase 1 (the chains the packed
+// launch completed) on a second stream BESIDE the resume launch, phase 2 (the chains that yielded) behind it; phase 0 = no split (every
+// other launch shape).  resume_t[ch] is -1 for a completed chain, the interval it resumes at otherwise.
+__device__ __forceinline__ bool wrong_phase(const ChainBufs& cb, int64_t ch, int phase) {
+    return phase != 0 && ((cb.resume_t[ch] >= 0) != (phase == 2));
 }
 
 // ---- replicate epilogue pieces ----
@@ -2067,9 +2197,10 @@ __device__ __forceinline__ bool trunk_active(const ChainBufs& cb, int64_t n_cand
 }
 
 __device__ __forceinline__
-void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ params, const ChainBufs& cb, int64_t ch, double* lds) {
+void trunk_body(const DevModel& m, int64_t n_cand, const double* __restrict__ params, const ChainBufs& cb, int64_t ch, double* lds, int phase = 0) {
     const int lane = lane_id();
     if (!trunk_active(cb, n_cand) || ch >= cb.n_chains[0]) return;
+    if (wrong_phase(cb, ch, phase)) return;
     double* xbuf = lds;
     double* lcb = lds + 128;
     const int ft = cb.fail_t[ch];
@@ -2269,10 +2400,10 @@ void correct_follow_kernel(DevModel m, int64_t n_items, ChainBufs cb, const doub
 // costs a queue round trip, which is what limits the rate when many batches are in flight.
 template <bool CPFIT, int GROUP>
 __global__ __launch_bounds__(64)
-void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, int64_t trunk_blocks, const double* __restrict__ split_time, const double* __restrict__ params) {
+void post_kernel(DevModel m, int64_t n_cand, ChainBufs cb, int64_t trunk_blocks, const double* __restrict__ split_time, const double* __restrict__ params, int phase) {
     extern __shared__ double lds[];
-    if ((int64_t)blockIdx.x < trunk_blocks) trunk_body(m, n_cand, params, cb, (int64_t)blockIdx.x, lds);
-    else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - trunk_blocks, lds);
+    if ((int64_t)blockIdx.x < trunk_blocks) trunk_body(m, n_cand, params, cb, (int64_t)blockIdx.x, lds, phase);
+    else correct_body<CPFIT, GROUP, true>(m, n_cand, cb, split_time, params, (int64_t)blockIdx.x - trunk_blocks, lds, nullptr, nullptr, nullptr, nullptr, 0, 0, phase);
 }
 
 // Default fit only: the rates after the split (FitSinglePop, CorrectLambda.py:82-92, called at MigrationInference.py:361-364).
@@ -2326,13 +2457,17 @@ __global__ __launch_bounds__(WPB * 64, 4)      // 4 waves per SIMD: a 4 096-cand
 void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ order, const double* __restrict__ split_time, const double* __restrict__ params,
                      ChainBufs cb, double* __restrict__ lc_out, double* __restrict__ pr_out,
                      double* __restrict__ jafs_out, int32_t* __restrict__ status_out, double* __restrict__ diag_out,
-                     int n_inline, const double* __restrict__ jsfs, const double* __restrict__ consts, double* __restrict__ llk_out) {
+                     int n_inline, const double* __restrict__ jsfs, const double* __restrict__ consts, double* __restrict__ llk_out, int phase) {
     extern __shared__ double lds[];
     const int lane = lane_id();
     // everything per candidate is wave-uniform: keep it in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t slot = (int64_t)blockIdx.x * WPB + wave;
     if (slot >= n_cand) return;
+    if (phase != 0) {                              // two-phase launch (wrong_phase): a candidate of the other phase's chains leaves at once
+        const int64_t cd = (int64_t)__builtin_amdgcn_readfirstlane(order[slot]);
+        if (wrong_phase(cb, (int64_t)__builtin_amdgcn_readfirstlane((int)chain_of(cb, cd)), phase)) return;
+    }
 #ifdef MISTI_STAMP2
     long long s_[8];
 #define KSTAMP(i) s_[i] = clock64();
@@ -2819,20 +2954,58 @@ __global__ __launch_bounds__(256) void llh_const_kernel(int64_t n_rep, const dou
 }
 
 // llk[c][r] = const[r] + sum_i data[r][i] log JAFS[c][i]  (folded: pairs 0+6, 1+5, 2+4, 3)
-// MigrationInference.py:600-609.  One block = one candidate x LLK_TILE replicates;
-// writes are 8 B per lane, coalesced along r.
+// MigrationInference.py:600-609.  The one HBM-WRITE-bound kernel of the path: 8 bytes out per value, 56 bytes of
+// spectrum in per CANDIDATE and 72 bytes of data in per REPLICATE.  So the replicate is what a thread keeps: thread = two adjacent
+// replicates (their class counts and constants in registers, read once), block = 512 replicates x a CHUNK of candidates whose
+// class logs the block computes once into LDS; per value that leaves 4 (folded) or 7 fused multiply-adds and one half of a
+// 16-byte store, 1 KB contiguous per wave-instruction, streamed past the caches (nontemporal: nothing reads llk in this kernel).
+// Round 4's kernel gave every value its own 64-byte read of the replicate row - 4.7 GB through L2 for 0.5 GB written.
+// Same expressions as llk_of / log_class (the inline epilogue of spectrum_kernel): the same bits.
+constexpr int LLK_CHUNK_MAX = 64;      // candidates per block at most (class logs in LDS: 64 x 7 doubles)
+template <bool UNFOLDED>
 __global__ __launch_bounds__(256)
-void llk_kernel(int64_t n_cand, const double* __restrict__ jafs, const int32_t* __restrict__ status,
+void llk_kernel(int64_t n_cand, int chunk, const double* __restrict__ jafs, const int32_t* __restrict__ status,
                 int64_t n_rep, const double* __restrict__ jsfs, const double* __restrict__ consts,
-                double* __restrict__ llk, int unfolded) {
-    __shared__ double lj[7];
-    const int64_t c = blockIdx.y;
-    const int st = status ? status[c] : MISTI_OK;
-    if (threadIdx.x < 7) lj[threadIdx.x] = log_class(jafs + c * 7, threadIdx.x, unfolded);
+                double* __restrict__ llk) {
+    constexpr int NF = UNFOLDED ? 7 : 4;
+    __shared__ double lj[LLK_CHUNK_MAX][8];           // [7] = 1.0 where the candidate has no value (status != OK), else 0.0
+    const int64_t c0 = (int64_t)blockIdx.y * chunk;
+    const int nc = (int)(n_cand - c0 < chunk ? n_cand - c0 : chunk);
+    for (int i = threadIdx.x; i < nc * 8; i += blockDim.x) {
+        const int c = i >> 3, k = i & 7;
+        double v;
+        if (k < 7) v = log_class(jafs + (c0 + c) * 7, k, UNFOLDED ? 1 : 0);
+        else v = (status && status[c0 + c] != MISTI_OK) ? 1.0 : 0.0;
+        lj[c][k] = v;
+    }
+    // this thread's two replicates: class counts (folded: the four sums) and constants
+    const int64_t r0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    double f[2][NF], cst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t r = r0 + u < n_rep ? r0 + u : (n_rep - 1);         // a lane beyond the table repeats the last row (never stored)
+        const double* d = jsfs + r * 8 + 1;
+        cst[u] = consts[r];
+        if (UNFOLDED) { for (int i = 0; i < 7; ++i) f[u][i] = d[i]; }
+        else { f[u][0] = d[0] + d[6]; f[u][1] = d[1] + d[5]; f[u][2] = d[2] + d[4]; f[u][3] = d[3]; }
+    }
     __syncthreads();
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (int64_t)gridDim.x * blockDim.x) {
-        const double out = (st != MISTI_OK) ? -INFINITY : llk_of(jsfs + r * 8, consts[r], lj, unfolded);
-        llk[c * n_rep + r] = out;
+    if (r0 >= n_rep) return;
+    const bool pair = r0 + 1 < n_rep && (n_rep & 1) == 0;                  // both in range and every row 16-byte aligned
+    double* out = llk + c0 * n_rep + r0;
+    for (int c = 0; c < nc; ++c, out += n_rep) {
+        double a0 = cst[0], a1 = cst[1];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) { const double l = lj[c][i]; a0 = fma(f[0][i], l, a0); a1 = fma(f[1][i], l, a1); }
+        if (lj[c][7] != 0.0) { a0 = -INFINITY; a1 = -INFINITY; }
+        if (pair) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 v; v.x = a0; v.y = a1;
+            __builtin_nontemporal_store(v, (d2*)out);
+        } else {
+            __builtin_nontemporal_store(a0, out);
+            if (r0 + 1 < n_rep) __builtin_nontemporal_store(a1, out + 1);
+        }
     }
 }
 
@@ -2917,6 +3090,7 @@ Tuning read_tuning() {
     t.yield_nfev = getenv("MISTI_YIELD_NFEV") ? num("MISTI_YIELD_NFEV") : -1;
     t.k2_single_waves = getenv("MISTI_K2_SINGLE_WAVES") ? num("MISTI_K2_SINGLE_WAVES") : -1;
     t.pairing = !(getenv("MISTI_FOLLOW_PAIRING") && getenv("MISTI_FOLLOW_PAIRING")[0] == '0');
+    t.two_phase = !(getenv("MISTI_TWO_PHASE") && getenv("MISTI_TWO_PHASE")[0] == '0');
     return t;
 }
 
@@ -2925,10 +3099,11 @@ static size_t trunk_lds_bytes(int numT) { return (128 + 2 * (size_t)(numT + 1)) 
 
 template <bool CPFIT, int GROUP>
 static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, int yield_nfev,
-                            hipStream_t stream) {
+                            hipStream_t stream, hipEvent_t after_packed) {
     const int per_wave = 64 / GROUP;
     dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
     hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params, yield_nfev);
+    if (after_packed) (void)hipEventRecord(after_packed, stream);             // phase 1 of what follows the chains starts here, beside the resume launch
     if (yield_nfev > 0 && GROUP != 64) {
         // the chains that yielded, one per wave: as many workgroups as are resident (two waves per SIMD for --cpfit, one for the
         // default fit); those beyond the list's length leave at once
@@ -2946,13 +3121,13 @@ bool trunk_follows(int cpw_chains, int64_t trunk_cap, const Tuning& tn) {
 }
 
 template <bool CPFIT, int GROUP>
-static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, bool follow, hipStream_t stream) {
+static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params, bool follow, hipStream_t stream, int phase) {
     const int per_wave = 64 / GROUP;
     const int64_t trunk_blocks = follow ? 0 : cb.trunk_cap;
     dim3 grid((unsigned)(trunk_blocks + (n_cand + per_wave - 1) / per_wave));
     size_t lds = correct_lds_bytes(m.numT);
     if (trunk_lds_bytes(m.numT) > lds) lds = trunk_lds_bytes(m.numT);
-    hipLaunchKernelGGL((post_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, cb, trunk_blocks, split, params);
+    hipLaunchKernelGGL((post_kernel<CPFIT, GROUP>), grid, dim3(64), lds, stream, m, n_cand, cb, trunk_blocks, split, params, phase);
 }
 
 #define MISTI_DISPATCH_GROUP(FN, ...)                                                                   \
@@ -2968,7 +3143,7 @@ static void launch_post_t(const DevModel& m, int64_t n_cand, const ChainBufs& cb
 // cpw: chains per wavefront, chosen by the caller from the expected number of chains
 // est_chains: chains of the previous batch of this size on the context, or < 0 when unknown
 hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb, const double* split, const double* params,
-                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream) {
+                          int cpw, bool follow, int64_t est_chains, const Tuning& tn, int yield_nfev, hipStream_t stream, hipEvent_t after_packed) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     if (follow) {
@@ -2987,7 +3162,7 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
         else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
         return hipGetLastError();
     }
-    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, yield_nfev, stream)
+    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, yield_nfev, stream, after_packed)
     return hipGetLastError();
 }
 
@@ -3003,12 +3178,12 @@ int64_t trunk_capacity(int64_t n_cand, const Tuning& tn) {
 hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* order, const double* split, const double* params,
                            const ChainBufs& cb, double* lc_out, double* pr_out, double* jafs, int32_t* status, double* diag,
                            int64_t n_rep, const double* jsfs, const double* consts, double* llk, bool follow, bool skip_post, bool single_waves,
-                           const Tuning& tn, hipStream_t stream) {
+                           const Tuning& tn, hipStream_t stream, int phase) {
     if (n_cand <= 0) return hipSuccess;
     const bool cp = m.flags & MISTI_CPFIT;
     const int cpw = correct_cands_per_wave(n_cand, tn);          // tails: one item per candidate
     // skip_post: the caller knows there is nothing for the post launch to do (no trunk left for it and no fractional split: run_dev)
-    if (!skip_post) { MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream) }
+    if (!skip_post) { MISTI_DISPATCH_GROUP(launch_post_t, m, n_cand, cb, split, params, follow, stream, phase) }
     if (!cp) {
         const int64_t threads = n_cand * (int64_t)(m.numT + 1);
         hipLaunchKernelGGL(postsplit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, m, n_cand, split, params, cb);
@@ -3018,7 +3193,7 @@ hipError_t launch_spectrum(const DevModel& m, int64_t n_cand, const int32_t* ord
     dim3 grid((unsigned)((n_cand + wpb - 1) / wpb));
 #define MISTI_SPECTRUM_LAUNCH(CP, W)                                                                                                   \
     hipLaunchKernelGGL((spectrum_kernel<CP, W>), grid, dim3(W * 64), spectrum_lds_bytes(m.numT, W), stream,                            \
-                       m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk)
+                       m, n_cand, order, split, params, cb, lc_out, pr_out, jafs, status, diag, n_inline, jsfs, consts, llk, phase)
     if (cp) { if (single_waves) MISTI_SPECTRUM_LAUNCH(true, 1); else MISTI_SPECTRUM_LAUNCH(true, WAVES_PER_BLOCK); }
     else { if (single_waves) MISTI_SPECTRUM_LAUNCH(false, 1); else MISTI_SPECTRUM_LAUNCH(false, WAVES_PER_BLOCK); }
 #undef MISTI_SPECTRUM_LAUNCH
@@ -3041,12 +3216,17 @@ hipError_t launch_llh_const(int64_t n_rep, const double* jsfs, double* consts, i
 hipError_t launch_llk(int64_t n_cand, const double* jafs, const int32_t* status, int64_t n_rep, const double* jsfs,
                       const double* consts, double* llk, int unfolded, hipStream_t stream) {
     if (n_cand <= 0 || n_rep <= 0) return hipSuccess;
-    unsigned bx = (unsigned)((n_rep + 255) / 256);
-    if (bx > 64) bx = 64;
-    for (int64_t c0 = 0; c0 < n_cand; c0 += 65535) {
-        int64_t nc = n_cand - c0 < 65535 ? n_cand - c0 : 65535;
-        hipLaunchKernelGGL(llk_kernel, dim3(bx, (unsigned)nc), dim3(256), 0, stream,
-                           nc, jafs + c0 * 7, status ? status + c0 : nullptr, n_rep, jsfs, consts, llk + c0 * n_rep, unfolded);
+    // block = 512 replicates x `chunk` candidates: as large a chunk as still leaves the chip a few thousand blocks (a block's
+    // set-up - the class logs of its chunk, the rows of its replicates - is paid once per chunk)
+    const int64_t tiles = (n_rep + 511) / 512;
+    int64_t chunk = n_cand * tiles / 4096;
+    chunk = chunk < 4 ? 4 : (chunk > LLK_CHUNK_MAX ? LLK_CHUNK_MAX : chunk);
+    const int64_t per_launch = 65535 * chunk;                               // gridDim.y limit
+    for (int64_t c0 = 0; c0 < n_cand; c0 += per_launch) {
+        const int64_t nc = n_cand - c0 < per_launch ? n_cand - c0 : per_launch;
+        const dim3 grid((unsigned)tiles, (unsigned)((nc + chunk - 1) / chunk));
+        if (unfolded) hipLaunchKernelGGL(llk_kernel<true>, grid, dim3(256), 0, stream, nc, (int)chunk, jafs + c0 * 7, status ? status + c0 : nullptr, n_rep, jsfs, consts, llk + c0 * n_rep);
+        else hipLaunchKernelGGL(llk_kernel<false>, grid, dim3(256), 0, stream, nc, (int)chunk, jafs + c0 * 7, status ? status + c0 : nullptr, n_rep, jsfs, consts, llk + c0 * n_rep);
     }
     return hipGetLastError();
 }

@@ -231,6 +231,47 @@ def main():
                      "16 one-ulp-in-expm runs each, with solver traces")
         print("wrote %d cases -> %s" % (len(cases), path))
         return
+    if mode == "extra":
+        # Round 5: candidates the first pass flags once the contract's factor is 3 (tests/parity.py) that have no study yet, in a file of their
+        # own (golden_fullsize_r05.json): `extra config3 13340 config2:default 97 225 ...`; --cpfit workloads at the depth of `study`, default-fit ones
+        # at the depth of `default`.
+        jobs, spec = [], None
+        for a in sys.argv[2:]:
+            if a.lstrip("-").isdigit():
+                deep = not spec.endswith(":default")
+                jobs.append((spec, int(a), N_INPUT if deep else 16, N_INTERNAL, N_RESIDUAL if deep else 0, True))
+            else:
+                spec = a
+                if spec not in _W:
+                    _W[spec] = workload(spec)
+        path = os.path.join(HERE, "golden_fullsize_r05.json")
+        cases, traces = [], []
+        for c, tr in pool_map(_study_job, jobs, procs):
+            cases.append(c)
+            if tr:
+                traces.append(tr)
+        write_golden(path, cases, traces, "round 5: candidates of BASELINE's full-size grids the first pass (compiled baseline as checker, factor 3) put outside the contract "
+                     "and that had no reference-run study yet; --cpfit workloads with 64 + 16 + 16 runs, default-fit workloads with 16 + 16")
+        print("wrote %d cases -> %s" % (len(cases), path))
+        return
+    if mode == "default256":
+        # Round 5: default-fit evidence at BASELINE size - 256 candidates FIXED IN ADVANCE, evenly spaced over the grids of
+        # configs 2, 3 AND 5 under the reference's default fit (85 + 85 + 86; offset half a stride, as `default` above), each through
+        # /root/reference with 16 input perturbations + 16 one-ulp-in-expm runs and its solver trace.  No candidate is chosen by looking at a result.
+        jobs = []
+        for spec, n, k_n in (("config2:default", 4096, 85), ("config3:default", 16384, 85), ("config5:default", 65536, 86)):
+            _W[spec] = workload(spec)
+            jobs += [(spec, int(round((k + 0.5) * n / float(k_n))), 16, 16, 0, True) for k in range(k_n)]
+        path = os.path.join(HERE, "golden_default_fit_256.json")
+        cases, traces = [], []
+        for c, tr in pool_map(_study_job, jobs, procs):
+            cases.append(c)
+            if tr:
+                traces.append(tr)
+        write_golden(path, cases, traces, "256 candidates of BASELINE configs 2, 3 and 5 under the reference's DEFAULT fit (MiSTI.py:86,213), evenly spaced and fixed in "
+                     "advance (85 + 85 + 86), through /root/reference with 16 input perturbations and 16 one-ulp-in-expm runs each, with solver traces")
+        print("wrote %d cases -> %s" % (len(cases), path))
+        return
     if mode == "patch-failures":
         # golden file written before failing cases got their perturbed runs: add them in place
         path = os.path.join(HERE, sys.argv[2])
@@ -249,7 +290,7 @@ def main():
         json.dump(d, open(path, "w"))
         print("patched %d failing cases in %s" % (len(done), path))
         return
-    raise SystemExit("mode: values | study | default | patch-failures")
+    raise SystemExit("mode: values | study | default | default256 | patch-failures")
 
 
 if __name__ == "__main__":

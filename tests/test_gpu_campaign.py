@@ -54,7 +54,9 @@ def test_random_batches_against_the_oracle(seed):
     ref = rc.load_ref(os.path.join(GOLDEN, "campaign_seed%d.json.gz" % seed), 600, seed, n_jobs)
     rep = rc.compare(cases, ref)
     s = rep["stats"]
-    record("campaign_seed%d" % seed, **{k: int(v) for k, v in s.items()}, outside_list=[(int(b[2]), float(b[0])) for b in rep["outside"]])
+    record("campaign_seed%d" % seed, **{k: int(v) for k, v in s.items()}, outside_list=[(int(b[2]), float(b[0])) for b in rep["outside"]],
+           outside_detail=[dict(idx=int(b[2]), model=int(b[3]), cand=int(b[4]), rel=float(b[0]), spread=float(b[1]), factor=float(b[0] / b[1]) if b[1] else None,
+                                run=float(b[6]), cpfit=bool(b[7])) for b in rep["outside"]])
     assert s["candidates"] == n_jobs == want["n"]
     # a failure against a value only where the reference (its restatement) itself flips in its 32 runs: none measured, none allowed
     assert s["status_mismatch"] == 0, rep["bad"][:5]

@@ -1,6 +1,6 @@
 """BASELINE configs 3, 4 and 5 at FULL size through the C ABI, a sample of each against the oracle
 (config 2 is in test_gpu_grid.py).  Same contract: statuses equal; llk within 1e-9 (+ rounding
-floor) where the reference is determined; runaway-rate candidates under the per-candidate contract (10 x that candidate's own
+floor) where the reference is determined; runaway-rate candidates under the per-candidate contract (SELF_FACTOR x that candidate's own
 spread, measured at test time through the compiled baseline); plus the properties each workload offers at full size."""
 import numpy as np
 import pytest
@@ -24,13 +24,15 @@ def evaluate(name):
 
 # regular candidates of each sample beyond 1e-9 against the oracle, measured on MI355X (profiles/r04_measured_guards.jsonl); the guard is measured + 1
 REGULAR_BEYOND_MEASURED = {"config3": 0, "config4": 0, "config5": 0}
+# candidates of the 64-start sample of config 3 pinned outside the contract (index: measured relative distance x 1.5); see DESIGN.md section 2
+KNOWN_OUTSIDE_CONFIG3 = {}
 
 
-def against_oracle(w, res, n_sample, unfolded=False, min_regular=8, max_outside=0):
+def against_oracle(w, res, n_sample, unfolded=False, min_regular=8, known_outside=()):
     """A sample against the NumPy/SciPy oracle (statuses; 1e-9 wherever the reference is determined) AND, for the candidates
     whose corrected rate ran away, the per-candidate contract through the compiled baseline: 1e-9 or 10 x THAT candidate's own
-    spread under eight 2^-48 perturbations (tests/parity.py: baseline_contract) - no blanket tolerance.  max_outside = measured
-    on MI355X with this round's build + 1."""
+    spread under eight 2^-48 perturbations and eight one-ulp-in-expm runs (tests/parity.py: baseline_contract) - no blanket tolerance.
+    known_outside: {candidate: measured distance} of the sample's candidates pinned outside the contract."""
     from oracle.batch import oracle_batch
     idx = np.linspace(0, w.n_cand - 1, n_sample).astype(int)
     o_llk, o_st, _ = oracle_batch(w, idx, processes=8)
@@ -46,16 +48,19 @@ def against_oracle(w, res, n_sample, unfolded=False, min_regular=8, max_outside=
             if run[k] < RUNAWAY:
                 n_reg += 1
                 if err > llk_tol(o_llk[k, r], w.jsfs[r], res.jafs[c], unfolded):
-                    n_out += 1                                            # a gtol stop/continue flip (see test_gpu_grid.py)
-                    assert err <= 1e-8 * abs(o_llk[k, r]), (c, r, res.llk[c, r], o_llk[k, r])
+                    n_out += 1                                            # a gtol stop/continue flip (see test_gpu_grid.py): held to the contract below
     name = w.name.split(":")[0]
     record("against_oracle_" + name, regular=n_reg, regular_beyond_1e9=n_out)
     assert n_reg >= min_regular and n_out <= REGULAR_BEYOND_MEASURED[name] + 1
     rep = baseline_contract(w, idx, res.llk, res.status)
+    record("contract_" + name, tight=rep["tight"], self_bound=rep["self_bound"], worst_factor=float(rep["factor"].max()),
+           outside={str(int(idx[k])): [float(rep["rel"][k]), float(rep["factor"][k]), float(rep["run"][k])] for k in rep["outside"]})
     assert len(rep["mismatch"]) == 0
-    assert len(rep["outside"]) <= max_outside, [(int(idx[k]), float(rep["rel"][k]), float(rep["run"][k])) for k in rep["outside"]]
+    # an outside candidate is accepted only when it is PINNED: known by index, with its measured distance as the bound (each has a
+    # reference-run study among the full-size goldens, tests/test_gpu_fullsize.py) - no blanket tolerance, no anonymous allowance
     for k in rep["outside"]:
-        assert rep["run"][k] >= RUNAWAY and rep["rel"][k] <= 1e-5, (int(idx[k]), rep["rel"][k], rep["run"][k])
+        c = int(idx[k])
+        assert c in known_outside and rep["rel"][k] <= known_outside[c], (c, float(rep["rel"][k]), float(rep["factor"][k]), float(rep["run"][k]))
     return idx, o_st
 
 
@@ -63,7 +68,7 @@ def test_config3_random_starts():
     """16 384 random two-band starts, every start its own chain (no sharing): the packed kernel-1 path."""
     w, res = evaluate("config3")
     assert w.n_cand == 16384
-    against_oracle(w, res, 64, min_regular=40, max_outside=2)        # measured: 1 (start 1300: 1.2e-6, rate x length 7 033)
+    against_oracle(w, res, 64, min_regular=40, known_outside=KNOWN_OUTSIDE_CONFIG3)
     ok = res.status == 0
     assert ok.mean() > 0.95
     np.testing.assert_allclose(res.jafs[ok].sum(axis=1), 1.0, rtol=1e-12)
@@ -77,7 +82,7 @@ def test_config4_bootstrap_scan():
     chain for the whole batch, the separate replicate kernel."""
     w, res = evaluate("config4")
     assert res.llk.shape == (256, w.jsfs.shape[0]) and w.jsfs.shape[0] >= 1000
-    against_oracle(w, res, 24, min_regular=24 * 5, max_outside=0)
+    against_oracle(w, res, 24, min_regular=24 * 5)
     assert (res.status == 0).all()
     # replicate epilogue: llk is linear in the replicate's counts given the spectrum -> row 0 (the sum of the
     # chunks the others were resampled from) is reproduced from the spectrum by the host formula
@@ -95,7 +100,7 @@ def test_config5_pulse_grid_ancient_sample():
     """32 x 64 x 32 split x rate x pulse grid with an ancient sample (65 536 candidates, 2 048 chains)."""
     w, res = evaluate("config5")
     assert w.n_cand == 65536
-    against_oracle(w, res, 64, min_regular=20, max_outside=1)        # measured: 0
+    against_oracle(w, res, 64, min_regular=20)
     ok = res.status == 0
     assert ok.mean() > 0.9
     np.testing.assert_allclose(res.jafs[ok].sum(axis=1), 1.0, rtol=1e-12)

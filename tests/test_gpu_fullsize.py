@@ -37,7 +37,7 @@ MEASURED = {"config2": dict(both=4096, tight=3584, outside=0),
 def studied(workload):
     """Candidates of `workload` that /root/reference itself was run on (name -> case)."""
     out = {}
-    for f in ("golden_fullsize.json", "golden_default_fit.json"):
+    for f in ("golden_fullsize.json", "golden_default_fit.json", "golden_default_fit_256.json", "golden_fullsize_r05.json"):
         p = os.path.join(GOLDEN, f)
         if os.path.exists(p):
             for c in json.load(open(p))["cases"]:

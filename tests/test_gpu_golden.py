@@ -16,6 +16,7 @@ SWEEP = load_golden("golden_sweep")
 CAMPAIGN = load_golden("golden_campaign")
 FULLSIZE = load_golden("golden_fullsize")
 DEFAULT_FIT = load_golden("golden_default_fit")
+DEFAULT_FIT_256 = load_golden("golden_default_fit_256")
 
 
 def run_case(case):
@@ -113,6 +114,39 @@ def test_default_fit_at_baseline_size(case):
         assert case["out"]["llh"] is None and np.isfinite(llh) and m.status == 0
         pytest.xfail("documented deviation: the reference fails in all 33 runs (second root beyond a pole of its residual), the device returns a value")
     check(case)
+
+
+@pytest.mark.parametrize("case", DEFAULT_FIT_256, ids=[c["name"] for c in DEFAULT_FIT_256])
+def test_default_fit_256_fixed_in_advance(case):
+    """Round 5: 256 candidates of BASELINE configs 2, 3 AND 5 under the reference's default fit, evenly spaced and fixed
+    before any result existed (85 + 85 + 86; tests/golden/make_fullsize.py default256), each through /root/reference with 16 input
+    perturbations + 16 one-ulp-in-expm runs and its solver trace.  Every candidate under the contract, one by one."""
+    check(case)
+
+
+def test_default_fit_256_factor_distribution():
+    """How much of clause 2 the 256 fixed candidates use: |device - reference| in units of the reference's own spread (the larger of its
+    input-perturbation and one-ulp-in-expm spreads).  Recorded for profiles/r05_default_fit_256.txt; the guard is the contract's factor."""
+    from parity import SELF_FACTOR, record
+    factors, tight, status_pairs = [], 0, {}
+    for case in DEFAULT_FIT_256:
+        m, llh, _ = run_case(case)
+        o = case["out"]
+        key = ("value" if o["llh"] is not None else "failed", "value" if llh != -np.inf else "failed")
+        status_pairs[key] = status_pairs.get(key, 0) + 1
+        if o["llh"] is None or llh == -np.inf:
+            continue
+        rel = abs(llh - o["llh"]) / abs(o["llh"])
+        sp = max(spread_of(o) or 0.0, internal_of(o) or 0.0)
+        if rel <= 1e-9:
+            tight += 1
+        elif sp > 0:
+            factors.append(rel / sp)
+    f = np.sort(np.array(factors))
+    record("default_fit_256", comparable=tight + len(f), within_1e9=tight, status={"%s/%s" % k: v for k, v in status_pairs.items()},
+           factor_quantiles={q: float(np.quantile(f, q)) for q in (0.5, 0.9, 0.99, 1.0)} if len(f) else {},
+           within_1x=int((f <= 1).sum()), within_3x=int((f <= 3).sum()))
+    assert len(f) + tight >= 190 and (len(f) == 0 or f.max() <= SELF_FACTOR)
 
 
 def test_c_example(tmp_path):

@@ -42,8 +42,7 @@ def test_grid_sample_against_oracle(cfg2):
             # a stop/continue flip of SciPy's gtol test (|J^T f| within rounding of 1e-10) moves llk by up to a few
             # 1e-9; observed on ~0.1 % of regular candidates.  Everything else meets the 1e-9 contract.
             if err > llk_tol(o_llk[k, 0], w.jsfs[0], res.jafs[c], False):
-                n_out += 1
-                assert err <= 1e-8 * abs(o_llk[k, 0]), (c, res.llk[c, 0], o_llk[k, 0])
+                n_out += 1                      # held to the per-candidate contract below, like every other candidate of the sample
             else:
                 np.testing.assert_allclose(res.jafs[c], oracle_batch.last_jafs[k], rtol=1e-9)
     record("test_grid_sample_against_oracle", regular=n_reg, regular_beyond_1e9=n_out)
@@ -52,9 +51,8 @@ def test_grid_sample_against_oracle(cfg2):
     # runaway-rate candidates: the per-candidate contract (1e-9, or 10 x that candidate's own spread under eight 2^-48
     # perturbations, measured here through the compiled baseline).  Measured on MI355X: 85 tight, 11 within their spread, none outside
     rep = baseline_contract(w, idx, res.llk, res.status)
-    assert len(rep["mismatch"]) == 0 and len(rep["outside"]) <= 1, [(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]]
-    for k in rep["outside"]:
-        assert rep["run"][k] >= RUNAWAY and rep["rel"][k] <= 1e-5, (int(idx[k]), rep["rel"][k], rep["run"][k])
+    record("test_grid_sample_contract", tight=rep["tight"], self_bound=rep["self_bound"], outside=[int(idx[k]) for k in rep["outside"]], worst_factor=float(rep["factor"].max()))
+    assert len(rep["mismatch"]) == 0 and len(rep["outside"]) == 0, [(int(idx[k]), float(rep["rel"][k]), float(rep["factor"][k])) for k in rep["outside"]]
     # the engine's own diagnostic agrees with the oracle's measure of the same quantity
     ok = (o_st == 0)
     both_small = (run[ok] < 4.0) & (res.runaway[idx][ok] < 4.0)
@@ -94,9 +92,19 @@ def test_time_scale_invariance(cfg2):
         r2 = e2.evaluate(w.split_time, w.params / a, w.jsfs)
     ok = (res.status == 0) & (r2.status == 0)
     assert (res.status == r2.status).mean() > 0.99
-    d = np.abs(r2.jafs[ok] / res.jafs[ok] - 1).max(axis=1)
-    assert np.quantile(d, 0.8) < 1e-12          # exact up to rounding for regular candidates
-    assert (d < 1e-3).all()                     # runaway-rate candidates: noise-driven stopping point
+    d = np.full(w.n_cand, 0.0)
+    d[ok] = np.abs(r2.jafs[ok] / res.jafs[ok] - 1).max(axis=1)
+    assert np.quantile(d[ok], 0.8) < 1e-12      # exact up to rounding for regular candidates
+    # The others are runaway-rate candidates, whose stopping point is noise-driven in the reference itself: no invariance to claim, but
+    # the evaluation on the RESCALED inputs must meet the per-candidate contract on those inputs (1e-9, or SELF_FACTOR x that candidate's
+    # own spread, through the compiled baseline) - no blanket tolerance.
+    moved = np.where(ok & (d >= 1e-9))[0]
+    assert (res.runaway[moved] >= RUNAWAY).all()
+    if len(moved):
+        from types import SimpleNamespace
+        w2 = SimpleNamespace(**{**w.__dict__, "times": list(np.array(w.times) * a), "lh": [list(x) for x in np.array(w.lh) / a], "params": w.params / a})
+        rep = baseline_contract(w2, moved, r2.llk, r2.status)
+        assert len(rep["mismatch"]) == 0 and len(rep["outside"]) == 0, [(int(moved[k]), float(rep["rel"][k]), float(rep["factor"][k])) for k in rep["outside"]]
 
 
 def test_population_swap_symmetry(cfg2):
@@ -112,9 +120,17 @@ def test_population_swap_symmetry(cfg2):
         r2 = e2.evaluate(w.split_time, w.params, w.jsfs)
     perm = [2, 5, 0, 3, 6, 1, 4]
     ok = (res.status == 0) & (r2.status == 0)
-    d = np.abs(r2.jafs[ok][:, perm] / res.jafs[ok] - 1).max(axis=1)
-    assert np.quantile(d, 0.8) < 1e-11
-    assert (d < 1e-3).all()
+    d = np.full(w.n_cand, 0.0)
+    d[ok] = np.abs(r2.jafs[ok][:, perm] / res.jafs[ok] - 1).max(axis=1)
+    assert np.quantile(d[ok], 0.8) < 1e-11
+    # runaway-rate candidates: the swapped evaluation under the per-candidate contract on the swapped inputs (see test_time_scale_invariance)
+    moved = np.where(ok & (d >= 1e-9))[0]
+    assert (res.runaway[moved] >= RUNAWAY).all()
+    if len(moved):
+        from types import SimpleNamespace
+        w2 = SimpleNamespace(**{**w.__dict__, "lh": [list(x) for x in lh], "bands": bands})
+        rep = baseline_contract(w2, moved, r2.llk, r2.status)
+        assert len(rep["mismatch"]) == 0 and len(rep["outside"]) == 0, [(int(moved[k]), float(rep["rel"][k]), float(rep["factor"][k])) for k in rep["outside"]]
 
 
 def test_replicate_linearity(cfg2):

@@ -5,7 +5,7 @@ import io
 import numpy as np
 import pytest
 
-from parity import llk_tol
+from parity import adhoc_workload, baseline_contract, llk_tol
 
 pytestmark = pytest.mark.gpu
 
@@ -27,7 +27,9 @@ def test_largest_grid_against_oracle():
     with Engine(inp.times, inp.lambdas, [(0, 3, -1, 0.0, 0)], [], n_param=1, cpfit=True, smooth=True) as e:
         res = e.evaluate(np.repeat(splits, 2), np.tile([0.05, 0.2], len(splits)).reshape(-1, 1), [row], want_lc=True)
     checked = 0
-    for c, (s, p) in enumerate(zip(np.repeat(splits, 2), np.tile([0.05, 0.2], len(splits)))):
+    all_split, all_par = np.repeat(splits, 2), np.tile([0.05, 0.2], len(splits))
+    loose, loose_want = [], []
+    for c, (s, p) in enumerate(zip(all_split, all_par)):
         m = OracleModel(list(inp.times), [list(x) for x in inp.lambdas], row, float(s), [[1, 3, int(np.ceil(s)), float(p), 1]], [],
                         cpfit=True, smooth=True)
         want = m.jafs_likelihood([float(p)])
@@ -35,12 +37,19 @@ def test_largest_grid_against_oracle():
             assert res.status[c] != 0
             continue
         assert res.status[c] == 0
-        if res.runaway[c] < 5.0:
+        if abs(res.llk[c, 0] - want) <= llk_tol(want, row, m.JAFS, False):
             checked += 1
-            assert abs(res.llk[c, 0] - want) <= llk_tol(want, row, m.JAFS, False), (s, p)
         else:
-            assert abs(res.llk[c, 0] - want) <= 1e-3 * abs(want)
+            assert res.runaway[c] >= 5.0, (s, p, res.llk[c, 0], want)      # beyond 1e-9 only where a corrected rate ran away ...
+            loose.append(c)
+            loose_want.append(want)
     assert checked >= 4
+    if loose:
+        # ... and there under the per-candidate contract (tests/parity.py): within SELF_FACTOR x that candidate's own spread, measured
+        # here by 16 + 16 perturbed runs of the compiled baseline; the value it is held to stays the oracle's.  No blanket tolerance.
+        w = adhoc_workload(inp.times, inp.lambdas, [(0, 3, -1, 0.0, 0)], [], 1, dict(cpfit=True, smooth=True), 0, all_split, all_par.reshape(-1, 1), row)
+        rep = baseline_contract(w, np.array(loose), res.llk, res.status, kinds=16, internal=16, ref_llk=np.array(loose_want), ref_status=np.zeros(len(loose), dtype=np.int32))
+        assert len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0, [(loose[k], float(rep["rel"][k]), float(rep["factor"][k])) for k in rep["outside"]]
     # one interval more is refused when the context is created
     from misti_amd._lib import MistiError
     big = grid(129, 128)
@@ -72,9 +81,14 @@ def test_largest_model_structure():
             assert res.status[0] == m.status if hasattr(m, "status") else res.status[0] != 0
             continue
         assert res.status[0] == 0
-        assert abs(res.llk[0, 0] - want) <= llk_tol(want, row, m.JAFS, False) or res.runaway[0] >= 5.0
-        if "true_eps" in kw_e:
-            assert abs(res.llk[0, 0] - want) <= llk_tol(want, row, m.JAFS, False)
+        if "true_eps" in kw_e or abs(res.llk[0, 0] - want) > llk_tol(want, row, m.JAFS, False):
+            if "true_eps" in kw_e:
+                assert abs(res.llk[0, 0] - want) <= llk_tol(want, row, m.JAFS, False)
+            else:
+                # the per-candidate contract: SELF_FACTOR x this candidate's own spread (16 + 16 runs of the compiled baseline), the value the oracle's
+                w = adhoc_workload(inp.times, inp.lambdas, bands, pulses, 16, kw_e, 0, [split], [par], row)
+                rep = baseline_contract(w, np.array([0]), res.llk, res.status, kinds=16, internal=16, ref_llk=np.array([want]), ref_status=np.array([0]))
+                assert len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0, (res.llk[0, 0], want, float(rep["rel"][0]), float(rep["factor"][0]))
     with pytest.raises(MistiError):
         Engine(inp.times, inp.lambdas, bands + [(0, 18, 19, 0.1, -1)], pulses, n_param=16, cpfit=True)
     with pytest.raises(MistiError):

@@ -93,6 +93,39 @@ def test_default_fit_iteration_at_baseline_size():
     assert n_equal >= DEFAULT_FIT_EQUAL_MEASURED[0] * 0.97 * n_solves and n_mig_equal >= DEFAULT_FIT_EQUAL_MEASURED[1] * 0.97 * n_mig, (n_equal, n_solves, n_mig_equal, n_mig)
 
 
+def test_default_fit_iteration_256_fixed_candidates():
+    """The same comparison on round 5's 256 candidates fixed in advance over configs 2, 3 and 5 (golden_default_fit_256.json): (nfev, status) of
+    every least_squares call of the reference against the device's solver word of the same interval; recorded per workload."""
+    from parity import record
+    traces = _baseline_size_traces("golden_default_fit_256_traces.json.gz")
+    cases = [c for c in load_golden("golden_default_fit_256") if c["name"] in traces]
+    assert len(cases) >= 190
+    from solver_trace_util import KIND_OF_SITE, hip_trace
+    tot = {}
+    for c in cases:
+        llh, m, tr = hip_trace(c)
+        if not np.isfinite(llh):
+            continue
+        wl = c["fullsize"]["workload"]
+        t_ = tot.setdefault(wl, dict(cases=0, solves=0, equal=0, migrating=0, migrating_equal=0, worst_nfev_difference=0))
+        t_["cases"] += 1
+        for sv in traces[c["name"]]["solves"]:
+            t = sv["t"]
+            hip = (int(tr["nfev"][0, t]), int(tr["status"][0, t]))
+            same = hip == (sv["nfev"], sv["status"]) and int(tr["kind"][0, t]) == KIND_OF_SITE[sv["site"]]
+            t_["solves"] += 1
+            t_["equal"] += same
+            if sv["site"] == "two_pop_ect":
+                t_["migrating"] += 1
+                t_["migrating_equal"] += same
+                t_["worst_nfev_difference"] = max(t_["worst_nfev_difference"], abs(hip[0] - sv["nfev"]))
+    record("default_fit_iteration_256", **tot)
+    n_solves, n_equal = sum(v["solves"] for v in tot.values()), sum(v["equal"] for v in tot.values())
+    n_mig, n_mig_equal = sum(v["migrating"] for v in tot.values()), sum(v["migrating_equal"] for v in tot.values())
+    assert n_mig > 5000
+    assert n_equal >= 0.85 * n_solves and n_mig_equal >= 0.70 * n_mig, (n_equal, n_solves, n_mig_equal, n_mig)
+
+
 # fraction of solves whose (nfev, status) equal the reference's: all solves / the migrating (two_pop_ect) ones; measured on MI355X, round 4
 DEFAULT_FIT_EQUAL_MEASURED = (0.901, 0.790)    # 4 693 of 5 207 solves; 1 938 of 2 452 migrating solves; largest |nfev difference| 20
 

@@ -14,6 +14,7 @@ PART=${2:-all}          # all | bench | trace | pmc
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+python3 -c "from misti_amd import _lib; print(_lib.build_id())" > "$OUT/build_id.txt"      # the counters below belong to THIS build (profiles/pmc_latest.json: build_id)
 SHORT="--steps 4 --warmup 2 --streams 1 --no-cpu-baseline --no-extra-legs --min-seconds 0"
 WORKLOADS="config2 config2x16 config3 config5"
 

@@ -14,20 +14,20 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from misti_amd import workloads
 from misti_amd.engine import Engine, truth_spectrum
-w = workloads.config2(lambda *a: truth_spectrum(*a))
+WL = next((a for a in sys.argv[1:] if not a.startswith("-")), "config2")        # config2 | config3 | config5
+w = getattr(workloads, WL)(lambda *a: truth_spectrum(*a))
 with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
     r = e.evaluate(w.split_time, w.params, w.jsfs, want_pr=True)
     work = r.pr[:, -1, :]         # per candidate: its chain's counters
     # unique chains by rate
-    rates = w.params[:, 0]
     rows = {}
     for k in range(w.n_cand):
-        rows[float(rates[k])] = work[k]
+        rows[tuple(float(v) for v in w.params[k])] = work[k]
     stamped = float(np.max(work[:, 4])) > 1e5          # cycle stamps, not counters
     tab = sorted(rows.items(), key=lambda kv: -(float(np.sum(kv[1])) if stamped else kv[1][0]))
     print("rate, c_tree, c_collect+c_update, c_next, c_adv, c_batch, c_book  (cycles; STAMP build; plain build: evals dense terms spec max_nfev lm)")
     for rate, wk in tab[:6] + tab[-3:]:
-        print("%.4g" % rate, " ".join("%.0f" % v for v in wk), ("total %.3g Mcycles" % (np.sum(wk) / 1e6)) if stamped else "", " per-pass: adv %.0f batch %.0f book %.0f" % tuple(wk[3:6] / max(wk[0], 1)))
+        print(" ".join("%.4g" % v for v in rate), " ".join("%.0f" % v for v in wk), ("total %.3g Mcycles" % (np.sum(wk) / 1e6)) if stamped else "", " per-pass: adv %.0f batch %.0f book %.0f" % tuple(wk[3:6] / max(wk[0], 1)))
     # timing serial
     dev = torch.device("cuda", 0)
     d_split = torch.as_tensor(w.split_time, device=dev); d_par = torch.as_tensor(w.params, device=dev).contiguous(); d_j = torch.as_tensor(w.jsfs, device=dev).contiguous()

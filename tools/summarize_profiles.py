@@ -96,7 +96,10 @@ def main():
     for wl in WORKLOADS:
         stats_csv(os.path.join(src, "trace_serial_" + wl), os.path.join(dst, "%s_kernel_stats_serial_%s.csv" % (tag, wl)))
     stats_csv(os.path.join(src, "trace_pipelined"), os.path.join(dst, tag + "_kernel_stats_pipelined.csv"))
-    latest = {"note": "per workload: HBM bytes per launch of the two big kernels (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, KB -> bytes) and the SQ "
+    bid = os.path.join(src, "build_id.txt")
+    build_id = open(bid).read().strip() if os.path.exists(bid) else None
+    latest = {"build_id": build_id,
+              "note": "per workload: HBM bytes per launch of the two big kernels (FETCH_SIZE x 2 gfx950 correction + WRITE_SIZE, KB -> bytes) and the SQ "
                       "counters of the same launches; bench.py reads this for roofline.traffic and roofline.valu (stored, not measured in the bench run)",
               "workloads": {}}
     for wl in WORKLOADS:
@@ -112,7 +115,7 @@ def main():
                 "their bytes (MI355X_MICROARCH.md, HBM section): doubled before comparing with a byte count. SQ_WAVE_CYCLES / SQ_WAIT_* / "
                 "SQ_ACTIVE_INST_* count quad-cycles, SQ_INSTS_* instructions per wave." % wl)
         json.dump({"note": note, "workload": wl, "counters": counters}, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
-        entry = {"source": "profiles/%s_pmc_%s.json" % (tag, wl)}
+        entry = {"source": "profiles/%s_pmc_%s.json" % (tag, wl), "build_id": build_id}
         for key, pats in (("correct", KERNEL1[wl]), ("post", ("misti::post_kernel",)), ("spectrum", ("misti::spectrum_kernel<true",))):
             hbm, v, names = 0.0, {}, []
             for pat in pats:
