@@ -25,12 +25,21 @@ def _internal_noise():
     return _NOISE
 
 
+def _wide_spread():
+    p = os.path.join(GOLDEN, "wide_spread.json")
+    return json.load(open(p))["cases"] if os.path.exists(p) else {}
+
+
 def load_golden(name):
     """Cases of tests/golden/<name>.json with the shared grids expanded."""
     d = json.load(open(os.path.join(GOLDEN, name + ".json")))
     grids = d.get("grids", {})
     noise = _internal_noise()
+    wide = _wide_spread()
     for c in d["cases"]:
+        w = wide.get(c["name"])
+        if w is not None and c["out"].get("llh") is not None:        # tests/golden/wide_spread.py: clause 2b, the reference under 2^-44 perturbations
+            c["out"]["spread_wide"] = w["spread_wide"]
         n = noise.get(c["name"])
         if n is not None and c["out"].get("llh") is not None:       # tests/golden/internal_noise.py: second measurement of the reference's indeterminacy
             c["out"]["internal_spread"], c["out"]["internal_fail"], c["out"]["internal_runs"] = n["internal_spread"], n["fails"], n["runs"]

@@ -27,14 +27,16 @@ pytestmark = pytest.mark.gpu
 
 # First pass, measured on MI355X with this round's build: candidates, comparable ones, within 1e-9, and the candidates OUTSIDE the
 # contract under the fixture's uniform spreads (candidate index -> measured relative distance), each of which is a reference-run golden.
-MEASURED = {1: dict(n=7648, comparable=7103, tight=5249, outside={5600: 1.75e-9, 5601: 1.88e-9, 5602: 2.04e-9, 5603: 2.30e-9, 5604: 1.23e-9}),
-            2: dict(n=7694, comparable=7080, tight=5379, outside={464: 1.85e-8, 466: 1.94e-8, 472: 2.38e-8, 476: 2.70e-8, 478: 2.64e-8, 480: 2.56e-8}),
-            3: dict(n=7434, comparable=6811, tight=5145, outside={3137: 1.62e-9}),
-            4: dict(n=7579, comparable=6779, tight=5097, outside={7331: 9.38e-8, 3867: 1.03e-9}),
-            5: dict(n=7561, comparable=6964, tight=5406, outside={3642: 1.87e-6, 559: 6.45e-8, 560: 6.54e-8, 561: 6.96e-8, 6935: 1.13e-9, 5877: 1.01e-9}),
-            # second held-out fixture, generated after everything above: the noise class now includes EVERY default-fit candidate (class version 2:
-            # the reference-run studies of seeds 1-5 showed the default fit without migration determined to 1e-9 ... 4e-9 only).  First pass: none outside.
-            6: dict(n=7372, comparable=6805, tight=5112, outside={})}
+MEASURED = {
+            1: dict(n=7648, comparable=7103, tight=5248, outside={2697: 7.41e-08, 2967: 5.73e-06, 2969: 5.17e-06, 2971: 4.23e-06, 2973: 3.84e-06, 2975: 3.72e-06, 4522: 8.85e-06, 5600: 1.75e-09, 5601: 1.88e-09, 5602: 2.04e-09, 5603: 2.3e-09, 5604: 1.23e-09}),
+            2: dict(n=7694, comparable=7080, tight=5375, outside={222: 6.35e-07, 464: 1.85e-08, 466: 1.94e-08, 472: 2.38e-08, 476: 2.7e-08, 478: 2.64e-08, 480: 2.56e-08, 484: 2.37e-08, 540: 6.97e-09, 1182: 5.85e-08, 2697: 3.48e-09}),
+            3: dict(n=7434, comparable=6811, tight=5147, outside={1876: 1.57e-08, 1880: 1.43e-08, 1882: 1.3e-08, 1886: 8.02e-09, 1888: 6.22e-09, 1890: 3.83e-09, 1892: 3.17e-09, 3137: 1.62e-09, 5270: 4.39e-08, 5271: 3.56e-08}),
+            4: dict(n=7579, comparable=6779, tight=5099, outside={3812: 2.32e-06, 3813: 1.44e-06, 3814: 8.22e-07, 3816: 6.06e-07, 3817: 5.99e-07, 3867: 1.03e-09, 7331: 3.54e-07}),
+            5: dict(n=7561, comparable=6964, tight=5405, outside={559: 6.45e-08, 560: 6.54e-08, 561: 6.96e-08, 3642: 1.85e-06, 5114: 4.63e-09, 5877: 1.01e-09, 6935: 1.13e-09}),
+            6: dict(n=7372, comparable=6805, tight=5111, outside={3735: 1.95e-05}),
+}
+# (round 4, factor 10: 5 / 6 / 1 / 2 / 6 / 0 outside.  Round 5, factor 3: 12 / 11 / 10 / 7 / 7 / 1 - whole chains fall out together: the members of
+# seed 1 model 229, seed 3 model 140, seed 4 model 303 share one chain each.  Seed 6 was generated after round 4's studies, seed 5 before them.)
 
 
 def studied():
@@ -55,8 +57,8 @@ def test_random_batches_against_the_oracle(seed):
     rep = rc.compare(cases, ref)
     s = rep["stats"]
     record("campaign_seed%d" % seed, **{k: int(v) for k, v in s.items()}, outside_list=[(int(b[2]), float(b[0])) for b in rep["outside"]],
-           outside_detail=[dict(idx=int(b[2]), model=int(b[3]), cand=int(b[4]), rel=float(b[0]), spread=float(b[1]), factor=float(b[0] / b[1]) if b[1] else None,
-                                run=float(b[6]), cpfit=bool(b[7])) for b in rep["outside"]])
+           outside_detail=[dict(idx=int(b[2]), model=int(b[3]), cand=int(b[4]), rel=float(b[0]), spread=None if b[1] is None else float(b[1]),
+                                factor=float(b[0] / b[1]) if b[1] else None, run=None if b[6] is None else float(b[6]), cpfit=bool(b[7])) for b in rep["outside"]])
     assert s["candidates"] == n_jobs == want["n"]
     # a failure against a value only where the reference (its restatement) itself flips in its 32 runs: none measured, none allowed
     assert s["status_mismatch"] == 0, rep["bad"][:5]

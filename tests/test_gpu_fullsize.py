@@ -22,25 +22,26 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from parity import KNOWN_STATUS, baseline_contract, record
+from parity import status_flips_wide, baseline_contract, record
 
 pytestmark = pytest.mark.gpu
 
-# measured on MI355X with this round's build (profiles/r04_fullsize_contract.txt, profiles/r04_measured_guards.jsonl):
-# candidates with a value on both sides, those within 1e-9, first-pass outside
+# measured on MI355X with this round's build (profiles/r05_measured_guards.jsonl; round 4: profiles/r04_fullsize_contract.txt):
+# candidates with a value on both sides, those within 1e-9, FIRST-PASS outside (against the compiled baseline, SELF_FACTOR = 3: round 4's
+# factor 10 gave 0 / 10 / 0 / 1).  Every first-pass outlier carries a reference-run study and lies inside the contract against the REFERENCE.
 MEASURED = {"config2": dict(both=4096, tight=3584, outside=0),
-            "config2:default": dict(both=3264, tight=0, outside=10),
+            "config2:default": dict(both=3264, tight=0, outside=23),
             "config5/16": dict(both=4080, tight=3168, outside=0),
-            "config3/4": dict(both=4078, tight=3705, outside=1)}        # start 9412: the device 2.3e-9 from the REFERENCE, the baseline 5.2e-6
+            "config3/4": dict(both=4078, tight=3703, outside=4)}        # starts 1300, 8868, 9412, 13340: the device 4e-12 ... 2e-9 from the REFERENCE
 
 
 def studied(workload):
-    """Candidates of `workload` that /root/reference itself was run on (name -> case)."""
+    """Candidates of `workload` that /root/reference itself was run on (candidate -> case)."""
+    from conftest import load_golden
     out = {}
-    for f in ("golden_fullsize.json", "golden_default_fit.json", "golden_default_fit_256.json", "golden_fullsize_r05.json"):
-        p = os.path.join(GOLDEN, f)
-        if os.path.exists(p):
-            for c in json.load(open(p))["cases"]:
+    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05"):
+        if os.path.exists(os.path.join(GOLDEN, f + ".json")):
+            for c in load_golden(f):
                 if c["fullsize"]["workload"] == workload:
                     out[int(c["fullsize"]["cand"])] = c
     return out
@@ -76,10 +77,10 @@ def check(key, workload, idx, rep):
         if o["llh"] is None or hs != 0:
             # a failure against a value: only where the reference itself flips under its perturbed runs
             flips = (o.get("pert_finite", 0) > 0 or o.get("internal_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0 or o.get("internal_fail", 0) > 0)
-            flips = flips or ref[cand]["name"] in KNOWN_STATUS          # the four documented status deviations (tests/parity.py)
+            flips = flips or status_flips_wide(ref[cand]["name"])       # the reference's own runs at 2^-40 ... 2^-32 (tests/parity.py)
             assert (o["llh"] is None) == (hs != 0) or flips, (cand, o["llh"], hs)
             continue
-        tol = max(1e-9 * abs(o["llh"]), SELF_FACTOR * max(o.get("spread") or 0.0, o.get("internal_spread") or 0.0) * abs(o["llh"]))
+        tol = max(1e-9 * abs(o["llh"]), SELF_FACTOR * max(o.get("spread") or 0.0, o.get("internal_spread") or 0.0, o.get("spread_wide") or 0.0) * abs(o["llh"]))
         assert abs(h - o["llh"]) <= tol, (cand, h, o["llh"], abs(h - o["llh"]) / abs(o["llh"]), o.get("spread"), o.get("internal_spread"))
 
 

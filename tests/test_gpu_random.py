@@ -40,14 +40,15 @@ def random_case(rng):
     return dict(times=times, lh=lh, sd=sd, split=float(split), bands=bands, pulses=pulses, P=P, flags=flags, params=params, sfs=sfs)
 
 
-# Measured on MI355X with this round's build (profiles/r04_measured_guards.jsonl): of the 120 models, those within 1e-9, those within 10 x
+# Measured on MI355X with this round's build (profiles/r04_measured_guards.jsonl): of the 120 models, those within 1e-9, those within SELF_FACTOR x
 # the oracle's own spread (eight 2^-48 input perturbations + eight one-ulp-in-expm runs, the same depth for every model that is not within
 # 1e-9), and those outside - pinned by their position in the sequence with the measured distance as the bound.
-MEASURED = dict(checked=120, tight=102, self_bound=11, outside={})
+MEASURED = dict(checked=120, tight=102, self_bound=10, wide=1, outside={})      # round 5, factor 3: model 25 (default fit) needs clause 2b
 
 
-def oracle_spread(c, o_llk, kinds=8, runs=8):
-    """The oracle's own indeterminacy for model c: largest |llk' - llk| over `kinds` input perturbations and `runs` one-ulp-in-expm runs."""
+def oracle_spread(c, o_llk, kinds=8, runs=8, size=None):
+    """The oracle's own indeterminacy for model c: largest |llk' - llk| over `kinds` input perturbations (of 2^-48; `size`: another
+    magnitude - clause 2b) and `runs` one-ulp-in-expm runs."""
     import oracle.misti_oracle as om
     from oracle.batch import oracle_eval
     from parity import perturbed
@@ -58,7 +59,7 @@ def oracle_spread(c, o_llk, kinds=8, runs=8):
             return oracle_eval(times, lh, c["bands"], c["pulses"], c["flags"], c["sd"], c["split"], c["params"], [c["sfs"]])
     vals, fails = [], 0
     for k in range(kinds):
-        v = ev(*perturbed(c["times"], c["lh"], k))
+        v = ev(*perturbed(c["times"], c["lh"], k, size))
         vals.append(v[0][0] if v[2] == 0 else None)
     for s in range(runs):
         rng = np.random.default_rng(7000 + s)
@@ -78,15 +79,15 @@ def oracle_spread(c, o_llk, kinds=8, runs=8):
 
 
 def test_random_models_against_oracle():
-    """The contract of tests/parity.py per model: 1e-9 (+ rounding floor), else within 10 x the oracle's own spread under eight
+    """The contract of tests/parity.py per model: 1e-9 (+ rounding floor), else within SELF_FACTOR (3) x the oracle's own spread under eight
     perturbations of 2^-48 of ITS inputs and eight runs with one ulp of noise in its pair-chain expm - the same depth for every model
     that needs it, computed here.  Guards = the measured counts; an outside model is pinned with its measured distance."""
-    from parity import SELF_FACTOR, record
+    from parity import PERTURB_WIDE, SELF_FACTOR, record
     from misti_amd.engine import Engine
     from oracle.batch import oracle_eval
     rng = np.random.default_rng(20240607)
-    n_checked = n_tight = n_self = n_fail_both = n_flip = 0
-    outside = {}
+    n_checked = n_tight = n_self = n_wide = n_fail_both = n_flip = 0
+    outside, wide_list = {}, {}
     for i in range(120):
         c = random_case(rng)
         with Engine(c["times"], c["lh"], c["bands"], c["pulses"], n_param=c["P"], sample_date=c["sd"], **c["flags"]) as e:
@@ -112,10 +113,17 @@ def test_random_models_against_oracle():
         spread, _, _ = oracle_spread(c, o_llk[0])
         if err <= SELF_FACTOR * spread:
             n_self += 1
+            continue
+        # clause 2b: the oracle's spread under input perturbations of 2^-44 (tests/parity.py: PERTURB_WIDE), for the models clause 2 leaves outside only
+        wide, _, _ = oracle_spread(c, o_llk[0], kinds=8, runs=0, size=PERTURB_WIDE)
+        if err <= SELF_FACTOR * wide:
+            n_wide += 1
+            wide_list[i] = (err / abs(o_llk[0]), spread / abs(o_llk[0]), wide / abs(o_llk[0]))
         else:
             outside[i] = (err / abs(o_llk[0]), spread / abs(o_llk[0]), run, c["flags"]["cpfit"])
-    record("test_random_models_against_oracle", checked=n_checked, tight=n_tight, self_bound=n_self, both_fail=n_fail_both, flips=n_flip,
-           outside={str(k): v for k, v in outside.items()})
+    record("test_random_models_against_oracle", checked=n_checked, tight=n_tight, self_bound=n_self, wide=n_wide, both_fail=n_fail_both, flips=n_flip,
+           outside={str(k): v for k, v in outside.items()}, wide_list={str(k): v for k, v in wide_list.items()})
+    assert n_wide <= MEASURED["wide"] + 1, wide_list
     assert n_checked == MEASURED["checked"]
     if MEASURED["tight"] is not None:
         assert n_tight >= MEASURED["tight"] - 1, (n_tight, n_self, outside)
