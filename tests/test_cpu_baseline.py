@@ -7,7 +7,9 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import determined, internal_of, llk_bound, spread_of
+from parity import SELF_FACTOR, determined, internal_of, llk_bound, spread_of, wide_of
+
+BASELINE_FACTOR = 10.0
 
 CASES = [c for f in ("golden_small", "golden_synthetic", "golden_sweep", "golden_campaign") for c in load_golden(f)]
 
@@ -42,7 +44,12 @@ def test_compiled_baseline_against_the_reference(case):
     if status[0] != 0:
         assert o.get("pert_fail", 0) > 0 or o.get("internal_fail", 0) > 0, (status[0], o["llh"])
         return
-    bound, clause = llk_bound(o["llh"], i["sfs"], o["JAFS"], flags["unfolded"], spread_of(o), internal_of(o))
+    bound, clause = llk_bound(o["llh"], i["sfs"], o["JAFS"], flags["unfolded"], spread_of(o), internal_of(o), wide_of(o))
+    if clause != "1e-9":
+        # The baseline is the first-pass CHECKER (its own Pade-13 expm and LU, its own rounding), not the product: it stays pinned at round 4's
+        # factor 10 - at the product's factor 3 it misses one golden itself (camp_s4_m581_c14, two-way --cpfit runaway: 7.5 x the reference's
+        # spread, where the HIP path's closed-form exponential is inside it).  Outliers of a first pass are judged by the reference, never by it.
+        bound *= BASELINE_FACTOR / SELF_FACTOR
     assert abs(llk[0, 0] - o["llh"]) <= bound, (llk[0, 0], o["llh"], bound, clause)
     if determined(o):
         np.testing.assert_allclose(jafs[0], o["JAFS"], rtol=1e-8)

@@ -9,7 +9,7 @@
 # one stream so that a launch's counters belong to that launch alone.  Under rocprofv3 the
 # program itself follows `--` (python3 bench.py ...): no env / bash -c hop.
 set -e -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}          # all | bench | trace | pmc
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -47,6 +47,17 @@ echo "kernel traces done"
 fi
 
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
+# the replicate epilogue (the HBM-write-bound kernel): bench.py --workload config4 runs misti_llk_dev at 256 x 1 000 and, last, at 65 536 x 1 000
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_llk" -- python3 bench.py --workload config4 --steps 4 --warmup 2 --streams 1 --no-cpu-baseline --min-seconds 0 > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_llk" -- python3 bench.py --workload config4 --steps 4 --warmup 2 --streams 1 --no-cpu-baseline --min-seconds 0 > /dev/null 2>> "$OUT/bench.err"
+echo "pmc llk done"
+# the default fit on the headline grid (no PMC pass existed for any default-fit workload)
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU \
+    --output-format csv -d "$OUT/pmc_sq_config2_default" -- python3 bench.py --workload config2 --fit default $SHORT > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT \
+    --output-format csv -d "$OUT/pmc_f64_config2_default" -- python3 bench.py --workload config2 --fit default $SHORT > /dev/null 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial_config2_default" -- python3 bench.py --workload config2 --fit default --streams 1 --steps 16 --warmup 4 --no-cpu-baseline --no-extra-legs --min-seconds 0 > "$OUT/bench_serial_prof_config2_default.json" 2>> "$OUT/bench.err"
+echo "pmc default fit done"
 for wl in $WORKLOADS; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$wl" -- python3 bench.py --workload $wl $SHORT > /dev/null 2>> "$OUT/bench.err"
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$wl" -- python3 bench.py --workload $wl $SHORT > /dev/null 2>> "$OUT/bench.err"

@@ -76,7 +76,7 @@ SQ = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     src = os.path.join(ROOT, "gpurun_out", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -141,6 +141,33 @@ def main():
                 entry[key + "_valu"] = v
         latest["workloads"][wl] = entry
         print("wrote %s_pmc_%s.json:" % (tag, wl), {k: v for k, v in entry.items() if k.endswith("per_launch")})
+    # the replicate epilogue at 65 536 spectra x 1 000 replicates (bench.py: llk_roofline_leg; its last launch under the two TCC passes)
+    llk = {}
+    for sub in ("pmc_write_llk", "pmc_fetch_llk"):
+        for k, d in pmc_last(os.path.join(src, sub)).items():
+            if k.startswith("misti::llk_kernel"):
+                llk.update(d)
+    if "WRITE_SIZE" in llk:
+        w, f = llk["WRITE_SIZE"] * 1024.0, 2.0 * llk.get("FETCH_SIZE", 0.0) * 1024.0
+        rec = {"kernel": "misti::llk_kernel", "spectra": 65536, "replicates": 1000, "WRITE_SIZE_KB": llk["WRITE_SIZE"], "FETCH_SIZE_KB": llk.get("FETCH_SIZE"),
+               "write_bytes": w, "fetch_bytes_corrected": f, "hbm_bytes_per_launch": w + f, "algorithmic_bytes": 8.0 * 65536 * 1000 + 56.0 * 65536 + 72.0 * 1000,
+               "grid_size": llk.get("grid_size"), "build_id": build_id,
+               "note": "rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE (separate passes) of `bench.py --workload config4 --streams 1 --steps 4`: the LAST launch of "
+                       "misti::llk_kernel = misti_llk_dev on 65 536 spectra x 1 000 replicates; KB as reported, FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md); "
+                       "16-byte-per-lane streaming stores, for which WRITE_SIZE is exact"}
+        json.dump(rec, open(os.path.join(dst, "%s_pmc_llk.json" % tag), "w"), indent=1)
+        latest["llk"] = rec
+        print("wrote %s_pmc_llk.json:" % tag, w + f, "bytes against", rec["algorithmic_bytes"], "algorithmic")
+    # the default fit on the headline grid
+    dcnt = {}
+    for sub in ("pmc_sq_config2_default", "pmc_f64_config2_default"):
+        for k, d in pmc_last(os.path.join(src, sub)).items():
+            dcnt.setdefault(k, {}).update(d)
+    if dcnt:
+        json.dump({"note": "rocprofv3 --pmc passes of `bench.py --workload config2 --fit default --streams 1 --steps 4`: per kernel, its last launch", "build_id": build_id,
+                   "counters": dcnt}, open(os.path.join(dst, "%s_pmc_config2_default.json" % tag), "w"), indent=1)
+        print("wrote %s_pmc_config2_default.json" % tag)
+    stats_csv(os.path.join(src, "trace_serial_config2_default"), os.path.join(dst, "%s_kernel_stats_serial_config2_default.csv" % tag))
     if latest["workloads"]:
         json.dump(latest, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
         print("wrote pmc_latest.json")
