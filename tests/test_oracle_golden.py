@@ -16,6 +16,7 @@ CAMPAIGN = load_golden("golden_campaign")
 # numT = 128 cases run through the reference in round 4 (tests/golden/make_fullsize.py); ~2 s of oracle each: every fourth / eighth one here
 FULLSIZE = load_golden("golden_fullsize")[::4]
 DEFAULT_FIT = load_golden("golden_default_fit")[::8]
+FULLSIZE_R05 = load_golden("golden_fullsize_r05")[::4]
 DEFAULT_FIT_256 = load_golden("golden_default_fit_256")[7::16]        # round 5's 256 fixed candidates (configs 2, 3 and 5, default fit): 16 of them here
 # the oracle restates the reference operation by operation on the same SciPy, so
 # agreement is at rounding level; 1e-12 leaves room for a different BLAS build
@@ -68,6 +69,12 @@ def test_sweep(case):
 def test_campaign_worst(case):
     """The random campaign's worst candidates (tools/random_campaign.py), run through the reference: the oracle the
     campaign is judged against reproduces the reference on them."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", FULLSIZE_R05, ids=[c["name"] for c in FULLSIZE_R05])
+def test_fullsize_outliers_round5(case):
+    """Round 5's reference-run studies of full-grid outliers: the oracle reproduces the reference on them."""
     check(case)
 
 
