@@ -423,7 +423,10 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     // completed - trunks, tails, the candidate kernel of their members: 91 % of BASELINE config 3 - runs on a second stream BESIDE the resume
     // launch, which is one chain latency long and leaves most of the chip idle; the members of the chains that yielded follow behind it on the
     // batch's own stream, which then waits for the second one.  MISTI_TWO_PHASE=0 keeps everything on one stream.
-    const bool two_phase = yield_nfev > 0 && (c->dm.flags & MISTI_CPFIT) && c->tune.two_phase;
+    // Only while NO other context of the process has a batch in flight: the second stream is one more hardware queue (a process gets 24, and
+    // twenty contexts with a second stream each collapse the overlapped rate: config 5 4.5e7 -> 2.9e7 evals/s measured), and beside other contexts'
+    // batches there is no idle chip to fill.
+    const bool two_phase = yield_nfev > 0 && (c->dm.flags & MISTI_CPFIT) && c->tune.two_phase && busy() == 0;
     if (two_phase) {
         if (!c->side_stream) HIP_TRY_EV(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking), a, b);
         if (!c->packed_ev) HIP_TRY_EV(hipEventCreateWithFlags(&c->packed_ev, hipEventDisableTiming), a, b);
