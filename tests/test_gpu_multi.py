@@ -200,3 +200,16 @@ def test_an_exception_in_a_worker_thread_fails_the_call_not_the_process(grid, mo
     monkeypatch.delenv("MISTI_MULTI_THROW_IN_WORKER")
     with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m:
         assert np.isfinite(m.evaluate(w.split_time, w.params, w.jsfs).llk).any()
+
+
+def test_c_example_gathered_on_the_devices(tmp_path):
+    """examples/multi_device_gather.c: misti_multi_eval_batch_dev + misti_multi_sync from plain C with its own device buffers (HIP runtime C
+    entry points) - the table gathered by RCCL inside the library equals one context's misti_eval_batch bit for bit, padding rows are NaN / -1."""
+    import subprocess
+    from test_host_cpu import _build_c_example
+    exe = _build_c_example(tmp_path, "multi_device_gather", hip_runtime=True)
+    r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(l.split(" = ") for l in r.stdout.splitlines() if " = " in l)
+    assert int(out["contexts"]) == 1 and int(out["identical"]) == 1 and int(out["rows_per_shard"]) == 12
+    assert abs(float(out["llh"]) - (-211.9189044185307)) <= 1e-9 * 212

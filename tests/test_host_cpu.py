@@ -154,13 +154,15 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
 
 
-def _build_c_example(tmp_path, name="anchor_a2"):
+def _build_c_example(tmp_path, name="anchor_a2", hip_runtime=False):
     import subprocess
     exe = str(tmp_path / name)
     libdir = os.path.dirname(_lib.lib_path())
     _lib.load()                                              # builds the library if it is missing
     cmd = ["gcc", "-Wall", "-Wextra", "-Werror", "-std=c99", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "examples", name + ".c"), "-L", libdir, "-lmisti_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    if hip_runtime:                                          # an example that holds device memory itself: the HIP runtime's C entry points
+        cmd += ["-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lm"]
     subprocess.run(cmd, check=True, capture_output=True)
     return exe
 
@@ -177,6 +179,10 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
     # ... and the multi-device form (misti_create_multi / misti_multi_eval_batch): same header, same behaviour without a device
     exe = _build_c_example(tmp_path, "multi_device")
     r = subprocess.run([exe, "0", "0"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+    # ... and the device-resident form with the RCCL gather inside the library (ABI 5): links against the HIP runtime for its own buffers
+    exe = _build_c_example(tmp_path, "multi_device_gather", hip_runtime=True)
+    r = subprocess.run([exe, "0"], capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stderr
 
 
