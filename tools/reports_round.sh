@@ -14,5 +14,5 @@ for wl in config2 config3 config5; do
   if [ -f scratch/libmisti_stamp.so ]; then MISTI_LIB_AB=1 MISTI_LIB=scratch/libmisti_stamp.so python3 tools/stamp_run.py $wl > "$OUT/stamp_$wl.txt" 2>> "$OUT/err.txt"; fi
   if [ -f scratch/libmisti_work.so ]; then MISTI_LIB_AB=1 MISTI_LIB=scratch/libmisti_work.so python3 tools/stamp_run.py $wl > "$OUT/work_$wl.txt" 2>> "$OUT/err.txt"; fi
 done
-if [ -x scratch/ub/exec_skip ]; then scratch/ub/exec_skip > "$OUT/exec_skip.txt" 2>> "$OUT/err.txt"; fi
+hipcc --offload-arch=gfx950 -O3 -o "$OUT/exec_skip" tools/ub/exec_skip.hip 2>> "$OUT/err.txt" && "$OUT/exec_skip" > "$OUT/exec_skip.txt" 2>> "$OUT/err.txt"
 echo "reports_round $TAG done"
