@@ -385,6 +385,9 @@ def main():
             them (measured: ~11 long kernels in flight on 12 own streams against ~6 on 16 pool streams)."""
             def __init__(self):
                 self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
+                # what a caller sweeping a grid knows about its own batches: the split times of this workload have no fractional part (the device
+                # verifies it per candidate); config 4's scan has fractional splits and says nothing
+                self.eng.set_hints(integer_splits=bool(np.all(w.split_time == np.floor(w.split_time))))
                 self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
                 # multi-GPU: the llk of `bucket` consecutive batches of this lane are gathered by ONE collective (a 32 KB all_gather
                 # per batch is pure latency on xGMI and costs a fifth of the rate); every batch's llk still reaches every rank

@@ -173,6 +173,16 @@ int misti_eval_batch_dev(misti_ctx* ctx, int64_t n_cand,
                          int64_t n_rep, const double* d_jsfs,
                          double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status);
 
+/* What the CALLER knows about the batches it issues on this context from now on (0 clears).  A batch is four launches on one stream and,
+ * with many contexts' batches in flight, every launch boundary costs a round of the queue scheduler (~0.4 ms measured with 20 busy
+ * queues): the launch that only exists for fractional split times is not made when the caller says there are none.
+ *   MISTI_HINT_INTEGER_SPLITS   no split time of any candidate has a fractional part (the usual sweep: `::: st 20 21 22`, README.md:113).
+ * The host-buffer form misti_eval_batch looks at its split times itself and needs no hint; the device-buffer form cannot (they live in
+ * HBM).  The hint is VERIFIED on the device: a candidate with a fractional split in a batch issued under it gets status
+ * MISTI_BAD_STRUCTURE and -inf - never a wrong value. */
+#define MISTI_HINT_INTEGER_SPLITS 1u
+int misti_set_hints(misti_ctx* ctx, uint32_t hints);
+
 /* Replicate epilogue alone: llk[c][r] from already computed spectra (device
  * pointers).  status may be NULL (all OK).  MigrationInference.py:600-609 + :217-227. */
 int misti_llk_dev(misti_ctx* ctx, int64_t n_cand, const double* d_jafs, const int32_t* d_status,

@@ -11,6 +11,7 @@ import os
 from . import build as _build
 
 CPFIT, TRUE_EPS, SMOOTH, UNFOLDED = 1, 2, 4, 8
+HINT_INTEGER_SPLITS = 1
 STATUS_TEXT = {
     0: "ok",
     1: "Hit negative value of migration rate",
@@ -58,6 +59,7 @@ SYMBOLS = {
     "misti_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "misti_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "misti_sync": (C.c_int, [C.c_void_p]),
+    "misti_set_hints": (C.c_int, [C.c_void_p, C.c_uint32]),
     "misti_eval_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "misti_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,

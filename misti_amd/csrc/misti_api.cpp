@@ -108,6 +108,7 @@ struct misti_ctx {
     hipEvent_t order_ev = nullptr;      // orders a replaced stream before its successor (misti_set_stream)
     hipEvent_t last_ev = nullptr;       // recorded behind every batch: lets OTHER contexts see whether this one has work in flight
     bool last_ev_set = false;
+    unsigned hints = 0;                 // misti_set_hints: what the caller knows about its batches (MISTI_HINT_INTEGER_SPLITS)
     hipStream_t side_stream = nullptr;  // phase 1 of a two-phase batch (run_dev): what follows the chains a packed launch completed, beside its resume launch
     hipEvent_t packed_ev = nullptr, side_ev = nullptr;
     DevBuf nm_f64, nm_i32;              // batched Nelder-Mead: simplices, points, counters (misti_nm_solve)
@@ -273,6 +274,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
     if (!d_split) return fail(MISTI_E_ARG, "split_time is NULL");
+    if (c->hints & MISTI_HINT_INTEGER_SPLITS) hints |= RUN_INTEGER_SPLITS;           // the caller's word (verified on the device: spectrum_kernel)
     if (c->dm.n_param > 0 && !d_params) return fail(MISTI_E_ARG, "params is NULL but the model has %d parameters", c->dm.n_param);
     if (n_rep > 0 && (!d_jsfs || !d_llk)) return fail(MISTI_E_ARG, "jsfs / llk is NULL with n_rep > 0");
     HIP_TRY(hipSetDevice(c->device));
@@ -325,6 +327,7 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
         cb.hint = c->hint_dev;
         cb.simd_load = c->tune.pairing ? pair_table(c->device) : nullptr;
         cb.bounds = c->dm.n_band > 0 ? d_bounds : nullptr;
+        cb.integer_splits = (hints & RUN_INTEGER_SPLITS) ? 1 : 0;
         cb.post_lam = nullptr;
         cb.post_word = nullptr;
         if (!(c->dm.flags & MISTI_CPFIT)) {
@@ -683,6 +686,13 @@ int misti_set_stream(misti_ctx* c, void* s) {
     return 0;
 }
 
+int misti_set_hints(misti_ctx* c, uint32_t hints) {
+    if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
+    if (hints & ~MISTI_HINT_INTEGER_SPLITS) return fail(MISTI_E_ARG, "unknown hint bits 0x%x", (unsigned)(hints & ~MISTI_HINT_INTEGER_SPLITS));
+    c->hints = hints;
+    return 0;
+}
+
 int misti_get_stream(misti_ctx* c, void** s) {
     if (!c || !s) return fail(MISTI_E_ARG, "ctx / output is NULL");
     *s = static_cast<void*>(c->stream);
@@ -829,10 +839,13 @@ int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const dou
         HIP_TRY(c->st_pr.reserve(pr_n * sizeof(double)));
         HIP_TRY(hipMemsetAsync(c->st_pr.p, 0, pr_n * sizeof(double), c->stream));
     }
+    // the split times are in host memory here: whether any has a fractional part is a glance (the device-buffer form needs misti_set_hints)
+    bool whole = true;
+    for (size_t i = 0; i < nc && whole; ++i) { const double st = split[idx ? (size_t)idx[i] : i]; whole = st == std::floor(st); }
     int r = run_dev(c, n_cand, c->st_split.as<double>(), P > 0 ? c->st_params.as<double>() : nullptr,
                     with_bounds ? c->st_bounds.as<int32_t>() : nullptr, n_rep,
                     nr ? c->st_jsfs.as<double>() : nullptr, nr ? c->st_llk.as<double>() : nullptr, c->st_jafs.as<double>(),
-                    lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>());
+                    lc ? c->st_lc.as<double>() : nullptr, pr ? c->st_pr.as<double>() : nullptr, c->st_status.as<int32_t>(), whole ? RUN_INTEGER_SPLITS : 0u);
     if (r) return r;
     char* hout = pinned ? static_cast<char*>(c->pin_out.p) : (idx ? heap_out.data() : nullptr);
     struct Back { void* user; size_t off, bytes, row; };

@@ -83,6 +83,8 @@ struct ChainBufs {
     int32_t seq;            // this batch's tag
     int32_t unsorted;       // the caller knows its batch has one split time: bit 0 - candidates are dispatched in their own order, bit 1 - chains in
                             // order of arrival (setup_kernel sorts neither)
+    int32_t integer_splits; // the caller (or the host-buffer entry point, which sees them) says no split time has a fractional part: no tail launch was
+                            // made, and a candidate that has one after all is refused (spectrum_kernel)
     const int32_t* bounds;  // [n][n_band][2] per-candidate (start, end) of every band, or NULL: the model's
     double* post_lam;       // [n][numT+1] default fit: rates after the split (postsplit_kernel -> spectrum kernel)
     int32_t* post_word;     // [n][numT+1] their solver words, or NULL (trace off)

@@ -2483,6 +2483,8 @@ void spectrum_kernel(DevModel m, int64_t n_cand, const int32_t* __restrict__ ord
     Grid G;
     const int32_t* bb = cb.bounds ? cb.bounds + cand * 2 * m.n_band : nullptr;
     int status = setup_candidate(m, split_time[cand], par, G, bb);
+    // a batch issued under "no fractional split times" (misti_set_hints; no tail launch was made) that has one after all: refused, never wrong
+    if (status == MISTI_OK && cb.integer_splits && G.ins >= 0) status = MISTI_BAD_STRUCTURE;
     Model mod{&m, par, G.split, {0, 0, 0, 0}};
     mod.bb = bb;
     mod.cache();

@@ -189,6 +189,12 @@ class Engine:
         _lib.check(self._lib.misti_get_stream(self._ctx, C.byref(h)))
         return h.value or 0
 
+    def set_hints(self, integer_splits=False):
+        """``misti_set_hints``: what the caller knows about the batches it will issue on this context (device-buffer form: the split times live in
+        HBM).  ``integer_splits``: no split time has a fractional part - the launch that only serves fractional splits is not made (a batch that
+        has one after all gets status 4 for that candidate, never a wrong value)."""
+        _lib.check(self._lib.misti_set_hints(self._ctx, _lib.HINT_INTEGER_SPLITS if integer_splits else 0))
+
     def evaluate_dev(self, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0, d_bounds=0):
         """``misti_eval_batch_dev``: raw device addresses (ints); asynchronous."""
         v = lambda p: C.c_void_p(int(p)) if p else None
