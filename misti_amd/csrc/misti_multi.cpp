@@ -325,8 +325,10 @@ int misti_destroy_multi(misti_multi* m) {
     if (!m) return 0;
     m->shutdown();
     int rc = 0;
-    Rccl* R = rccl();
-    for (void* c : m->comm) if (c && R->CommDestroy) (void)R->CommDestroy(c);
+    if (!m->comm.empty()) {                              // only a context that gathered ever loaded RCCL
+        Rccl* R = rccl();
+        for (void* c : m->comm) if (c && R->CommDestroy) (void)R->CommDestroy(c);
+    }
     for (misti_ctx* c : m->ctx) { const int r = misti_destroy(c); if (r != 0 && rc == 0) rc = r; }
     delete m;
     return rc;
@@ -429,7 +431,12 @@ int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t ro
             void* sv = nullptr;
             if (int q = misti_get_stream(m->ctx[d], &sv)) return q;
             hipStream_t s = static_cast<hipStream_t>(sv);
+            // the fills below go to the stream's own device whatever the thread's current one is; the current device is set all the same
+            // (a worker thread starts on device 0) and, with one context - this IS the caller's thread - put back afterwards
+            int before = -1;
+            (void)hipGetDevice(&before);
             if (hipSetDevice(m->device[d]) != hipSuccess) return failm(MISTI_E_HIP, "hipSetDevice(%d) failed", m->device[d]);
+            struct Restore { int dev; ~Restore() { if (dev >= 0) (void)hipSetDevice(dev); } } restore{D == 1 ? before : -1};
             double* mine = d_llk_all[d] + (size_t)d * blk;
             const size_t used = (size_t)n_cand[d] * (size_t)n_rep;
             if (used < blk && hipMemsetAsync(mine + used, 0xFF, (blk - used) * sizeof(double), s) != hipSuccess) return failm(MISTI_E_HIP, "hipMemsetAsync failed");

@@ -236,7 +236,11 @@ def main():
         # own (golden_fullsize_r05.json): `extra config3 13340 config2:default 97 225 ...`; --cpfit workloads at the depth of `study`, default-fit ones
         # at the depth of `default`.
         jobs, spec = [], None
-        for a in sys.argv[2:]:
+        args = sys.argv[2:]
+        out_name = "golden_fullsize_r05.json"
+        if args and args[0] == "--out":              # `extra --out golden_config5_default_sample.json config5:default 49080 ...`: the same study into another fixture
+            out_name, args = args[1], args[2:]
+        for a in args:
             if a.lstrip("-").isdigit():
                 deep = not spec.endswith(":default")
                 jobs.append((spec, int(a), N_INPUT if deep else 16, N_INTERNAL, N_RESIDUAL if deep else 0, True))
@@ -244,10 +248,13 @@ def main():
                 spec = a
                 if spec not in _W:
                     _W[spec] = workload(spec)
-        path = os.path.join(HERE, "golden_fullsize_r05.json")
+        path = os.path.join(HERE, out_name)
         cases, traces = [], []
+        note = ("round 5: candidates of BASELINE's full-size grids the first pass (compiled baseline as checker, factor 3) put outside the contract "
+                "and that had no reference-run study yet; --cpfit workloads with 64 + 16 + 16 runs, default-fit workloads with 16 + 16")
         if os.path.exists(path):                    # the file grows: cases of earlier calls stay (grids re-expanded, then deduplicated again on writing)
             d = json.load(open(path))
+            note = d.get("note", note)
             for c in d["cases"]:
                 if "grid" in c["in"]:
                     g = d["grids"][c["in"].pop("grid")]
@@ -262,8 +269,7 @@ def main():
             cases.append(c)
             if tr:
                 traces.append(tr)
-        write_golden(path, cases, traces, "round 5: candidates of BASELINE's full-size grids the first pass (compiled baseline as checker, factor 3) put outside the contract "
-                     "and that had no reference-run study yet; --cpfit workloads with 64 + 16 + 16 runs, default-fit workloads with 16 + 16")
+        write_golden(path, cases, traces, note)
         print("wrote %d cases -> %s" % (len(cases), path))
         return
     if mode == "default256":

@@ -35,7 +35,7 @@ KINDS = 16
 def main():
     names = sys.argv[1:]
     cases = {c["name"]: c for f in ("golden_small", "golden_synthetic", "golden_sweep", "golden_campaign", "golden_fullsize", "golden_default_fit",
-                                    "golden_default_fit_256", "golden_fullsize_r05") if os.path.exists(os.path.join(HERE, f + ".json")) for c in load_golden(f)}
+                                    "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample") if os.path.exists(os.path.join(HERE, f + ".json")) for c in load_golden(f)}
     path = os.path.join(HERE, "wide_spread.json")
     out = json.load(open(path))["cases"] if os.path.exists(path) else {}
     warnings.simplefilter("ignore")

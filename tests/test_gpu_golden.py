@@ -125,21 +125,30 @@ def test_fullsize_outliers_round5(case):
     check(case)
 
 
+# the ten of the twelve that lie beyond factor 3 (the other two - c61273, c65234 - are inside the contract: clause 2 and clause 2b)
+CONFIG5_DEFAULT_BEYOND_THREE = frozenset("config5_default_c%d" % c for c in (49080, 51128, 53176, 55224, 57272, 59320, 61368, 63416, 65272, 65464))
+
+
 @pytest.mark.parametrize("case", CONFIG5_DEFAULT, ids=[c["name"] for c in CONFIG5_DEFAULT])
-def test_config5_default_fit_sample_falls_out_at_three(case):
-    """WHAT FALLS OUT AT FACTOR 3 and is listed as such: BASELINE config 5 under the reference's default fit, every fourth
-    candidate (16 384) against the compiled baseline - 10 outside in the first pass, nine of them one chain (rate x length 3 852).  Against the
-    REFERENCE (16 + 16 runs each): 3.0 ... 3.3 x its own spread on seven, 5.8 ... 5.9 x on three - on seven of the ten the reference itself reports
-    "Lambda correction failed" in 8 ... 16 of its 16 one-ulp-in-expm runs (its value stands on a knife edge).  Not expected failures and not waved
-    through: held to ROUND 4's factor of 10 here, explicitly, with the factor recorded."""
-    from parity import record
+def test_config5_default_fit_first_pass_outliers(case):
+    """BASELINE config 5 under the reference's default fit, EVERY candidate (65 536, four strided GPU calls) against the compiled baseline at factor 3:
+    12 outside in the first pass (profiles/r05_fullsize_contract_config5_default_first_pass.txt), each through the REFERENCE here (16 + 16 runs, traces).
+    Two are inside the contract by the reference's own measurement (factor 1.4 under clause 2; 1.7 under clause 2b: its llk moves 6 x more at 2^-44).
+    WHAT FALLS OUT AT FACTOR 3 and is listed as such: ten - nine of them one chain (rate x length 3 852) - at 3.0 ... 3.3 x the
+    reference's own spread (seven) and 5.8 ... 5.9 x (three); on seven of the ten the reference itself reports "Lambda correction failed" in 8 ... 16 of
+    its 16 one-ulp-in-expm runs (its value stands on a knife edge).  Not expected failures and not waved through: those ten are held to ROUND 4's factor
+    of 10 here, explicitly and by name, with the factor recorded; everything else to the contract."""
+    from parity import SELF_FACTOR, record
     m, llh, _ = run_case(case)
     o = case["out"]
     assert o["llh"] is not None and np.isfinite(llh)
     sp = max(spread_of(o) or 0.0, internal_of(o) or 0.0, wide_of(o) or 0.0)
     rel = abs(llh - o["llh"]) / abs(o["llh"])
     record("config5_default_sample", case=case["name"], rel=rel, factor=rel / sp, internal_fail=o.get("internal_fail"), internal_runs=o.get("internal_runs"))
-    assert rel <= 10.0 * sp, (case["name"], rel, sp)
+    if case["name"] in CONFIG5_DEFAULT_BEYOND_THREE:
+        assert rel <= 10.0 * sp, (case["name"], rel, sp)
+    else:
+        assert rel <= SELF_FACTOR * sp, (case["name"], rel, sp)
 
 
 @pytest.mark.parametrize("case", DEFAULT_FIT, ids=[c["name"] for c in DEFAULT_FIT])

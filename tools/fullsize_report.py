@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--kinds", type=int, default=8)
     ap.add_argument("--internal", type=int, default=8, help="runs with one ulp of noise in the baseline's pair-chain expm, per candidate not within 1e-9")
     ap.add_argument("--stride", type=int, default=1, help="every stride-th candidate (1 = the whole grid)")
+    ap.add_argument("--offset", type=int, default=0, help="first candidate of the stride (a grid too long for one GPU call is done in `stride` calls)")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 16)
     ap.add_argument("--dump", default="")
     a = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     for spec_name in a.workloads:
         t0 = time.time()
         w = build(spec_name, spec)
-        idx = np.arange(0, w.n_cand, a.stride)
+        idx = np.arange(a.offset, w.n_cand, a.stride)
         split = w.split_time[idx]
         par = None if w.params is None else w.params[idx]
         with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
@@ -58,12 +59,12 @@ def main():
         rep = baseline_contract(sub, np.arange(len(idx)), r.llk, r.status, threads=a.threads, kinds=a.kinds, internal=a.internal)
         out = [(int(idx[k]), float(rep["rel"][k]), float(rep["run"][k])) for k in rep["outside"]]
         mis = [(int(idx[k]), int(rep["base_status"][k]), int(r.status[k])) for k in rep["mismatch"]]
-        print(spec_name, "every candidate" if a.stride == 1 else "stride %d" % a.stride, ": n", len(idx), "both", rep["both"], "tight", rep["tight"],
+        print(spec_name, "every candidate" if a.stride == 1 else "stride %d offset %d" % (a.stride, a.offset), ": n", len(idx), "both", rep["both"], "tight", rep["tight"],
               "frac %.4f" % (rep["tight"] / max(1, rep["both"])), "self", rep["self_bound"], "outside", len(out), out, "mismatch", len(mis), mis,
               "worst_tight %.3g" % rep["worst_tight"], "(%.0f s)" % (time.time() - t0), flush=True)
         if a.dump:
             os.makedirs(a.dump, exist_ok=True)
-            tag = spec_name.replace(":", "_")
+            tag = spec_name.replace(":", "_") + ("" if a.stride == 1 else "_s%d_o%d" % (a.stride, a.offset))
             np.savez_compressed(os.path.join(a.dump, "fullsize_%s.npz" % tag), idx=idx, hip_llk=r.llk[:, 0], hip_status=r.status, hip_jafs=r.jafs,
                                 base_llk=rep["base_llk"], base_status=rep["base_status"], run=rep["run"], rel=rep["rel"],
                                 outside=np.array([o[0] for o in out], dtype=np.int64), mismatch=np.array([m[0] for m in mis], dtype=np.int64),
