@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     // 2 an event per stream joined on one stream (device-side waits), hipStreamSynchronize of that one, then hipDeviceSynchronize
     const int wait_mode = argc > 2 ? atoi(argv[2]) : 0;
     if (argc > 3) hipSetDeviceFlags(atoi(argv[3]) ? hipDeviceScheduleSpin : hipDeviceScheduleBlockingSync);
+    const int use_graph = argc > 4 ? atoi(argv[4]) : 0;      // 1: the launches of a stream are ONE captured graph (hipGraphLaunch per stream)
     hipStream_t join;
     hipStreamCreateWithFlags(&join, hipStreamNonBlocking);
     std::vector<hipEvent_t> evs(32);
@@ -38,12 +39,28 @@ int main(int argc, char** argv) {
         std::vector<hipStream_t> st(N);
         for (auto& s : st) hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         for (auto& sh : shapes) {
+            std::vector<hipGraphExec_t> gx(N, nullptr);
+            if (use_graph) {
+                for (int i = 0; i < N; ++i) {
+                    hipGraph_t g;
+                    hipStreamBeginCapture(st[i], hipStreamCaptureModeThreadLocal);
+                    for (int k = 0; k < sh[0]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
+                    spin_kernel<<<20, 128, 0, st[i]>>>(ticks, stamps + 2 * i);
+                    for (int k = 0; k < sh[1]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
+                    hipStreamEndCapture(st[i], &g);
+                    hipGraphInstantiate(&gx[i], g, nullptr, nullptr, 0);
+                    hipGraphDestroy(g);
+                    hipGraphLaunch(gx[i], st[i]);            // first launch uploads
+                }
+                hipDeviceSynchronize();
+            }
             double best = 1e30;
             std::vector<double> starts;
             for (int rep = 0; rep < 5; ++rep) {
                 hipDeviceSynchronize();
                 const auto t0 = std::chrono::steady_clock::now();
                 for (int i = 0; i < N; ++i) {
+                    if (use_graph) { hipGraphLaunch(gx[i], st[i]); continue; }
                     for (int k = 0; k < sh[0]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
                     spin_kernel<<<20, 128, 0, st[i]>>>(ticks, stamps + 2 * i);
                     for (int k = 0; k < sh[1]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
@@ -72,6 +89,7 @@ int main(int argc, char** argv) {
                     starts.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
                 }
             }
+            for (auto g : gx) if (g) hipGraphExecDestroy(g);
             printf("N=%2d pre=%d post=%d  burst %.3f ms (issue %.0f us; last long kernel ends at %.0f us; final hipDeviceSynchronize %.0f us)  long-kernel starts [us]:",
                    N, sh[0], sh[1], best, starts[N + 2], starts[N], starts[N + 1]);
             for (int i = 0; i < N; ++i) printf(" %.0f", starts[i]);
