@@ -54,7 +54,10 @@ sys.path.insert(0, ROOT)
 # stream and, with several ranks, for RCCL's and torch's own streams.
 # (single rank with RCCL initialised and one all_gather per 8 batches of a lane: 16 lanes 2.76e7, 18 lanes 2.86e7,
 # 20 lanes 2.65e7, 22 lanes 2.80e7 evals/s against 2.97e7 without RCCL -> 18 with several ranks)
-DEFAULT_STREAMS = 20 if int(os.environ.get("WORLD_SIZE", "1")) <= 1 else 18
+# (round 5, the driver's shape --steps 20 --warmup 5 with RCCL initialised on one rank: 18 lanes 2.38e7, 19 lanes 2.40e7, 20 lanes 0.80e7 whatever
+# GPU_MAX_HW_QUEUES says - RCCL and c10d take the queues between 19 and 24; ONE collective for all lanes' batches instead of one per lane was
+# tried and is slower, 3.18 against 3.71e7 steady on 18 lanes: every lane then waits for the same collective)
+DEFAULT_STREAMS = 20 if (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "--force-dist" not in sys.argv) else 18
 HW_QUEUES = 24
 HW_QUEUE_SLACK = 4
 
