@@ -6,7 +6,7 @@ OUT=gpurun_out/${TAG}rep
 mkdir -p "$OUT"
 python3 tools/parity_report.py > "$OUT/parity_goldens.txt" 2> "$OUT/err.txt"
 echo "parity report done"
-for s in 1 2 3 4 5 6 7; do
+for s in 1 2 3 4 5 6 7 8; do
   python3 tools/random_campaign.py --ref tests/golden/campaign_seed$s.json.gz --models 600 --seed $s > "$OUT/random_campaign_seed$s.txt" 2>> "$OUT/err.txt"
 done
 echo "campaign reports done"
