@@ -67,13 +67,14 @@ def config1(spectrum_fn, n_sites=10 ** 6):
     return w
 
 
-def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0, cpfit=True):
+def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0, cpfit=True,
+            psmc_seeds=(1, 2), truth_seed=7):
     """numT = 128; grid of split index x rate of one band ``-mi 1 4 {st} {r} 1``, ``--cpfit`` (``cpfit=False``: the
     reference's default fit, MiSTI.py:86,213)."""
-    inp = synth.psmc_pair(64, 65)
+    inp = synth.psmc_pair(64, 65, seeds=psmc_seeds)
     band_truth = [(0, 4, true_split, true_rate, -1)]
     mis, pus = _mis_pus(band_truth, [], true_split)
-    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=truth_seed)
     jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
     splits = np.arange(first_split, first_split + n_split, dtype=np.float64)
     rates = np.logspace(-3, np.log10(max_rate), n_rate)
@@ -83,6 +84,15 @@ def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, t
                  dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
                  st.ravel().copy(), rr.ravel()[:, None].copy(), dict(split=true_split, rate=true_rate))
     w.jsfs = np.array([synth.counts_from_spectrum(jafs, n_sites)])
+    return w
+
+
+def config2b(spectrum_fn, cpfit=True):
+    """The headline grid's shape on OTHER data: other PSMC curves (seeds 3, 4), another true history (seed 8), true split 70, true rate 0.1, the
+    split axis 40 ... 103.  Made at the end of round 5 as a held-out instance: nothing in the kernels, the contract or the tests was tuned on it
+    (tools/fullsize_report.py config2b config2b:default; tests/golden/make_fullsize.py)."""
+    w = config2(spectrum_fn, first_split=40, true_split=70, true_rate=0.1, cpfit=cpfit, psmc_seeds=(3, 4), truth_seed=8)
+    w.name = "config2b: held-out instance of " + w.name
     return w
 
 

@@ -16,7 +16,8 @@ spec = 'config3:default'
 mf._W[spec] = mf.workload(spec)
 w, _ = mf._W[spec]
 out = {}
-for cand in (2398, 6761, 7005, 7734):
+CANDS = [int(a) for a in sys.argv[1:]] or [2398, 6761, 7005, 7734]     # later candidates: given on the command line, merged into the file
+for cand in CANDS:
     times, lam, sfs, split, mis, pus, kw, params = mf.reference_args(w, cand)
     base = mg.run_reference(times, lam, sfs, split, mis, pus, kw, params)["llh"]
     rec = {"base": base}
@@ -27,5 +28,8 @@ for cand in (2398, 6761, 7005, 7734):
         print(cand, e, sum(v is not None for v in vals), 'of 16 runs give a value', [round(v, 6) for v in vals if v is not None][:3], flush=True)
     out[cand] = rec
 parity.PERTURB = 2.0 ** -48
-json.dump({'generator': 'tests/golden/pole_reference_runs.py', 'scipy': '1.15.3', 'numpy': '2.2.6', 'note': NOTE, 'cases': {'config3_default_c%d' % k: v for k, v in out.items()}},
+_path = os.path.join(ROOT, 'tests', 'golden', 'golden_pole_crossing.json')
+_have = json.load(open(_path))['cases'] if os.path.exists(_path) else {}
+_have.update({'config3_default_c%d' % k: v for k, v in out.items()})
+json.dump({'generator': 'tests/golden/pole_reference_runs.py', 'scipy': '1.15.3', 'numpy': '2.2.6', 'note': NOTE, 'cases': _have},
           open(os.path.join(ROOT, 'tests', 'golden', 'golden_pole_crossing.json'), 'w'), indent=1)

@@ -8,8 +8,19 @@ import numpy as np
 from conftest import load_golden
 from solver_trace_util import load_traces, hip_trace, KIND_OF_SITE
 names = sys.argv[1:] or ['camp_m229_c5', 'camp_m353_c0', 'camp_s4_m303_c2', 'camp_s3_m417_c5', 'camp_m206_c21']
-cases = {c['name']: c for c in load_golden('golden_campaign')}
-traces = load_traces()
+import glob, gzip, json
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+cases, traces = {}, load_traces()
+for f in sorted(glob.glob(os.path.join(GOLDEN, 'golden_*.json'))):          # any fixture that holds the named cases (and its traces, if it has some)
+    try:
+        cs = load_golden(os.path.basename(f)[:-5])
+    except Exception:
+        continue
+    if isinstance(cs, list) and cs and isinstance(cs[0], dict) and 'name' in cs[0] and 'in' in cs[0]:
+        cases.update({c['name']: c for c in cs})
+        tp = f[:-5] + '_traces.json.gz'
+        if os.path.exists(tp):
+            traces.update({c['name']: c for c in json.load(gzip.open(tp, 'rt'))['cases']})
 for n in names:
     c = cases[n]; tr_ref = traces.get(n)
     llh, m, tr = hip_trace(c)
