@@ -123,7 +123,14 @@ KNOWN_OUTSIDE = {"config3_c3392": 1.7e-6, "config3_c5088": 7.3e-7, "config3_c836
 # perturbations of its inputs up to STATUS_PERTURB_MAX (2.3e-10 relative: below the 1e-9 the north star asks of the VALUE).  The four are data
 # now, not a whitelist: `status_flips_wide(name)` reads the committed reference runs.
 STATUS_PERTURB_MAX = 2.0 ** -32
-KNOWN_STATUS = frozenset()          # round 4: {"config3_default_c2398", "config3_default_c6761", "config3_default_c7005", "config3_default_c7734"}
+# Round 4's whitelist ({"config3_default_c2398", ..._c6761, ..._c7005, ..._c7734}) became data (status_flips_wide).  What is listed here since the end of
+# round 5 is different in kind: three starts of config 3 under the default fit on which /root/reference reports "Lambda correction failed" in ALL of its
+# 16 + 16 protocol runs AND in all 64 runs on inputs perturbed by 2^-48 ... 2^-32 (golden_pole_crossing.json), while the HIP path returns a value.  All three
+# fail in the reference's solve of interval 22 - rate x length 8.7e-5, the stalled regime (misti_kernels.hip: the stall rule) - where the root of the noise-free
+# residual lies at -82 ... -106 % of the starting rates: the reference's noisy steps carry it to a non-positive rate.  Starts 8953 and 10912 return a value
+# with or without the stall rule (the first-pass checker excused them before by its own flips: never reference-studied until now); 4908 failed on the device
+# too before the rule (its noise-free root is negative) and has a value with it.  Expected failures, by name (tests/test_gpu_golden.py), not waved through.
+KNOWN_STATUS = frozenset({"config3_default_c4908", "config3_default_c8953", "config3_default_c10912"})
 _POLE = None
 
 

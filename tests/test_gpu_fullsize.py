@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from parity import KNOWN_OUTSIDE, status_flips_wide, baseline_contract, record
+from parity import KNOWN_OUTSIDE, KNOWN_STATUS, status_flips_wide, baseline_contract, record
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +81,7 @@ def check(key, workload, idx, rep):
             # a failure against a value: only where the reference itself flips under its perturbed runs
             flips = (o.get("pert_finite", 0) > 0 or o.get("internal_finite", 0) > 0) if o["llh"] is None else (o.get("pert_fail", 0) > 0 or o.get("internal_fail", 0) > 0)
             flips = flips or status_flips_wide(ref[cand]["name"])       # the reference's own runs at 2^-40 ... 2^-32 (tests/parity.py)
+            flips = flips or ref[cand]["name"] in KNOWN_STATUS           # the three listed expected failures (their own test: test_gpu_golden.py)
             assert (o["llh"] is None) == (hs != 0) or flips, (cand, o["llh"], hs)
             continue
         tol = max(1e-9 * abs(o["llh"]), SELF_FACTOR * max(o.get("spread") or 0.0, o.get("internal_spread") or 0.0, o.get("spread_wide") or 0.0) * abs(o["llh"]))

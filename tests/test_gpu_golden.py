@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from parity import JAFS_RTOL, KNOWN_OUTSIDE, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of, status_flips_wide, wide_of
+from parity import JAFS_RTOL, KNOWN_OUTSIDE, KNOWN_STATUS, LC_RTOL, determined, engine_args, internal_of, llk_bound, spread_of, status_flips_wide, wide_of
 
 pytestmark = pytest.mark.gpu
 
@@ -122,6 +122,15 @@ def test_fullsize_outliers_round5(case):
             check(case)
         except AssertionError:
             pytest.xfail("the reference's own gain ratios there are set by the rounding error of its expm (profiles/r05_gain_ratio_survivors.txt): %.3g relative" % rel)
+        return
+    if case["name"] in KNOWN_STATUS:
+        # the reference fails in every one of its runs (also on inputs perturbed by up to 2^-32), the device returns a value (tests/parity.py: KNOWN_STATUS)
+        m, llh, _ = run_case(case)
+        assert case["out"]["llh"] is None and np.isfinite(llh)
+        try:
+            check(case)
+        except AssertionError:
+            pytest.xfail("the reference's solve of the stalled interval 22 ends at a non-positive rate in all of its 96 runs; the device returns %.6f" % llh)
         return
     check(case)
 
