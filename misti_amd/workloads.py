@@ -96,6 +96,14 @@ def config2b(spectrum_fn, cpfit=True):
     return w
 
 
+def config2c(spectrum_fn, cpfit=True):
+    """A second held-out instance, made AFTER the stall rule that config2b led to (PSMC seeds 5, 6; true history seed 9; true split 60, true rate 0.3; split
+    axis 36 ... 99): does what was learnt on config2b hold on data nobody has looked at?"""
+    w = config2(spectrum_fn, first_split=36, true_split=60, true_rate=0.3, cpfit=cpfit, psmc_seeds=(5, 6), truth_seed=9)
+    w.name = "config2c: second held-out instance of " + w.name
+    return w
+
+
 def config2x16(spectrum_fn, n_grid=16, **kw):
     """``n_grid`` config-2 grids with distinct rate axes in ONE batch (the README's ``st x mc x rates`` sweep as a caller
     with one large sweep issues it, /root/reference/README.md:113): grid g scales the rate axis by 1 + g/64, so every

@@ -12,7 +12,8 @@ import make_fullsize as mf
 import make_golden as mg
 import parity
 warnings.simplefilter('ignore')
-spec = 'config3:default'
+spec = os.environ.get('MISTI_POLE_SPEC', 'config3:default')      # later studies: another default-fit workload (names follow the fixtures': <workload>_default_c<candidate>)
+PREFIX = spec.replace(':', '_') + '_c'
 mf._W[spec] = mf.workload(spec)
 w, _ = mf._W[spec]
 out = {}
@@ -30,6 +31,6 @@ for cand in CANDS:
 parity.PERTURB = 2.0 ** -48
 _path = os.path.join(ROOT, 'tests', 'golden', 'golden_pole_crossing.json')
 _have = json.load(open(_path))['cases'] if os.path.exists(_path) else {}
-_have.update({'config3_default_c%d' % k: v for k, v in out.items()})
+_have.update({PREFIX + '%d' % k: v for k, v in out.items()})
 json.dump({'generator': 'tests/golden/pole_reference_runs.py', 'scipy': '1.15.3', 'numpy': '2.2.6', 'note': NOTE, 'cases': _have},
           open(os.path.join(ROOT, 'tests', 'golden', 'golden_pole_crossing.json'), 'w'), indent=1)

@@ -33,6 +33,9 @@ MEASURED = {"config2": dict(both=4096, tight=3584, outside=0),
             "config2:default": dict(both=3264, tight=6, outside=19),       # before the stall rule (misti_kernels.hip: correct_body): tight 0, outside 23
             # the HELD-OUT instance of the headline grid (workloads.config2b: other PSMC curves, another true history; made at the end of round 5)
             "config2b": dict(both=4096, tight=3359, outside=15),           # one chain (rate index 35), rate x length 509 ... 672: reference-studied, golden_config2b.json
+            # ... and the SECOND held-out instance, made after the stall rule (workloads.config2c): the whole grids by tools/fullsize_report.py - --cpfit 4 096 / 3 512 tight /
+            # 20 flagged (all <= 0.63 x the reference's spread), default fit 3 254 / 3 tight / 0 outside / 4 status cases (reference flips)
+            "config2c/4": dict(both=1024, tight=None, outside=21), "config2c:default/4": dict(both=813, tight=None, outside=0),
             "config2b:default/2": dict(both=1715, tight=None, outside=0),  # every second candidate; the whole grid (tools/fullsize_report.py): 3 429 / 5 tight / 0 outside - 270 outside before the stall rule
             "config5/16": dict(both=4080, tight=3168, outside=0),
             "config3/4": dict(both=4078, tight=3703, outside=4)}        # starts 1300, 8868, 9412, 13340: the device 4e-12 ... 2e-9 from the REFERENCE
@@ -42,7 +45,7 @@ def studied(workload):
     """Candidates of `workload` that /root/reference itself was run on (candidate -> case)."""
     from conftest import load_golden
     out = {}
-    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b"):
+    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c"):
         if os.path.exists(os.path.join(GOLDEN, f + ".json")):
             for c in load_golden(f):
                 if c["fullsize"]["workload"] == workload:
@@ -141,6 +144,19 @@ def test_held_out_grid_default_fit():
     check("config2b:default/2", "config2b:default", idx, rep)
     assert rep["both"] >= MEASURED["config2b:default/2"]["both"] - 20 and len(rep["mismatch"]) == 0
     assert len(rep["outside"]) <= 2
+
+
+@pytest.mark.parametrize("cpfit", [True, False])
+def test_second_held_out_grid(cpfit):
+    """`config2c`, every fourth candidate, both fits: every flagged candidate carries its reference-run study (golden_config2c.json) and lies inside the contract there."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = workloads.config2c(lambda *a: truth_spectrum(*a), cpfit=cpfit)
+    idx = np.arange(3, w.n_cand, 4)              # offset 3: the flagged candidates of the whole grid sit on odd rate columns
+    rep = full_contract(w, idx)
+    key = "config2c/4" if cpfit else "config2c:default/4"
+    check(key, "config2c" if cpfit else "config2c:default", idx, rep)
+    assert len(rep["outside"]) <= MEASURED[key]["outside"] + 1
 
 
 def test_config5_sample_every_candidate():

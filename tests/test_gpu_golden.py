@@ -20,6 +20,7 @@ DEFAULT_FIT_256 = load_golden("golden_default_fit_256")
 FULLSIZE_R05 = load_golden("golden_fullsize_r05")
 CONFIG5_DEFAULT = load_golden("golden_config5_default_sample")
 CONFIG2B = load_golden("golden_config2b")
+CONFIG2C = load_golden("golden_config2c")
 
 
 def run_case(case):
@@ -168,6 +169,14 @@ def test_held_out_grid_config2b(case):
     sampled through the reference: 3 beyond 3 x, up to 5.5 x its own spread) is what found the reference's STALLED solves on very short intervals (the stall rule,
     misti_kernels.hip: correct_body); with the rule none of 3 429 is outside.  Here: those 8 and the 15 candidates (one chain) the --cpfit first pass
     leaves outside, each against the REFERENCE's own value and spreads (16 + 16 runs; --cpfit: 64 + 16 + 16)."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG2C, ids=[c["name"] for c in CONFIG2C])
+def test_second_held_out_grid_config2c(case):
+    """`config2c`: a second held-out instance of the headline grid, made AFTER the stall rule that config2b led to (other PSMC curves again, another history) - does what
+    was learnt there hold on data nobody had looked at?  First pass: default fit 0 of 3 254 outside, 4 status cases (the reference returns a value itself in one of its
+    one-ulp runs / in 15 of 16 runs at 2^-40: golden_pole_crossing.json); --cpfit 20 flagged (19 one chain, rate x length 4e4), every one at <= 0.63 x the reference's own spread."""
     check(case)
 
 
