@@ -104,6 +104,20 @@ def config2c(spectrum_fn, cpfit=True):
     return w
 
 
+def config3b(spectrum_fn, cpfit=True):
+    """Held-out instance of config 3 (end of round 5, after the stall rule): other PSMC curves (seeds 3, 4), another true history (seed 8), other random starts (seed 6)."""
+    w = config3(spectrum_fn, seed=6, cpfit=cpfit, psmc_seeds=(3, 4), truth_seed=8)
+    w.name = "config3b: held-out instance of " + w.name
+    return w
+
+
+def config5b(spectrum_fn, cpfit=True):
+    """Held-out instance of config 5 (end of round 5, after the stall rule): other PSMC curves (seeds 3, 4), another true history (seed 8)."""
+    w = config5(spectrum_fn, cpfit=cpfit, psmc_seeds=(3, 4), truth_seed=8)
+    w.name = "config5b: held-out instance of " + w.name
+    return w
+
+
 def config2x16(spectrum_fn, n_grid=16, **kw):
     """``n_grid`` config-2 grids with distinct rate axes in ONE batch (the README's ``st x mc x rates`` sweep as a caller
     with one large sweep issues it, /root/reference/README.md:113): grid g scales the rate axis by 1 + g/64, so every
@@ -116,12 +130,12 @@ def config2x16(spectrum_fn, n_grid=16, **kw):
     return w
 
 
-def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6, cpfit=True):
+def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6, cpfit=True, psmc_seeds=(1, 2), truth_seed=7):
     """Two optimised bands, random starts (one batched simplex-vertex evaluation)."""
-    inp = synth.psmc_pair(64, 65)
+    inp = synth.psmc_pair(64, 65, seeds=psmc_seeds)
     band_truth = [(0, 4, true_split, 0.2, -1), (1, 10, true_split, 0.05, -1)]
     mis, pus = _mis_pus(band_truth, [], true_split)
-    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=truth_seed)
     jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
     rng = np.random.default_rng(seed)
     par = 10.0 ** rng.uniform(-3, 0, size=(n_start, 2))
@@ -149,14 +163,14 @@ def config4(spectrum_fn, n_split=256, n_rep=1000, true_split=50, cpfit=False, se
     return w
 
 
-def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true_split=80, n_sites=10 ** 6, cpfit=True):
+def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true_split=80, n_sites=10 ** 6, cpfit=True, psmc_seeds=(1, 2), truth_seed=7):
     """Ancient second genome (--sdate 40000) + --hetloss 0 0.1; split x band rate x pulse fraction."""
-    inp = synth.psmc_pair(64, 64, sample_date=40000.0, units=mio.Units(hetloss2=0.1))
+    inp = synth.psmc_pair(64, 64, seeds=psmc_seeds, sample_date=40000.0, units=mio.Units(hetloss2=0.1))
     sd = inp.sampleDateDiscr
     band_truth = [(0, sd + 2, true_split, 0.15, -1)]
     pulse_truth = [(1, sd + 10, 0.1, -1)]
     mis, pus = _mis_pus(band_truth, pulse_truth, true_split)
-    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=truth_seed)
     jafs = spectrum_fn(times, lh, true_split, band_truth, pulse_truth, sd)
     splits = np.arange(first_split, first_split + n_split, dtype=np.float64)
     rates = np.logspace(-3, 0, n_rate)

@@ -103,7 +103,11 @@ def perturbed(times, lambdas, kind, size=None):
 # expm at |M| = 1e4 ... 1e5.  The HIP path's closed form (1e-14 against 50 digits, tests/test_gpu_pair_exp.py) follows exact arithmetic.  Only an
 # implementation that repeats scipy's expm error bit for bit could repeat those decisions.  Expected failures with their measured distance as bound.
 # (camp_m148_c12, rounds 2 - 4's entry here, is inside the contract since the stiff two-way exponential is a closed form.)
-KNOWN_OUTSIDE = {"config3_c3392": 1.7e-6, "config3_c5088": 7.3e-7, "config3_c8365": 5.2e-6, "config3_c10056": 1.4e-6}
+# ... and three of the same class on the HELD-OUT instance of config 3 (workloads.config3b, 4 096 of its 16 384 starts sampled at the end of round 5): 4.0, 6.1 and 11 x
+# the reference's own 96-run spread; float64 against 50-digit gain ratios of their solves in profiles/r05_gain_ratio_config3b.txt (off by 0.03 - 0.04 around the 0.75 threshold).
+# On held-out data the rate of such candidates is 3 of 4 096 (BASELINE's own config 3: 4 of 16 384).
+KNOWN_OUTSIDE = {"config3_c3392": 1.7e-6, "config3_c5088": 7.3e-7, "config3_c8365": 5.2e-6, "config3_c10056": 1.4e-6,
+                 "config3b_c3748": 2.4e-6, "config3b_c10520": 3.9e-7, "config3b_c12832": 5.0e-6}
 
 
 # Default fit at numT = 128 (BASELINE config 3 under the reference's default fit, 16 384 candidates): four candidates on which the reference
