@@ -111,6 +111,13 @@ def config3b(spectrum_fn, cpfit=True):
     return w
 
 
+def config4b(spectrum_fn, cpfit=False):
+    """Held-out instance of config 4 (end of round 5): other PSMC curves (seeds 3, 4), another true history (seed 8), true split 61, another bootstrap table (seed 4)."""
+    w = config4(spectrum_fn, true_split=61, cpfit=cpfit, seed=4, psmc_seeds=(3, 4), truth_seed=8)
+    w.name = "config4b: held-out instance of " + w.name
+    return w
+
+
 def config5b(spectrum_fn, cpfit=True):
     """Held-out instance of config 5 (end of round 5, after the stall rule): other PSMC curves (seeds 3, 4), another true history (seed 8)."""
     w = config5(spectrum_fn, cpfit=cpfit, psmc_seeds=(3, 4), truth_seed=8)
@@ -147,11 +154,11 @@ def config3(spectrum_fn, n_start=16384, true_split=64, seed=5, n_sites=10 ** 6, 
     return w
 
 
-def config4(spectrum_fn, n_split=256, n_rep=1000, true_split=50, cpfit=False, seed=3, n_sites=10 ** 6):
+def config4(spectrum_fn, n_split=256, n_rep=1000, true_split=50, cpfit=False, seed=3, n_sites=10 ** 6, psmc_seeds=(1, 2), truth_seed=7):
     """No migration; split scan incl. fractional values x bootstrap replicates
     (test.bs/*no.mig.sh shape; replicate table as utils/generateJSFS_bs.py writes it)."""
-    inp = synth.psmc_pair(64, 65)
-    times, lh, _ = synth.self_consistent(inp, true_split)
+    inp = synth.psmc_pair(64, 65, seeds=psmc_seeds)
+    times, lh, _ = synth.self_consistent(inp, true_split, seed=truth_seed)
     jafs = spectrum_fn(times, lh, true_split, [], [], 0)
     row = synth.counts_from_spectrum(jafs, n_sites)
     table = mio.bootstrap_table(synth.chunk_rows(row, 20), n_rep - 1, random.Random(seed))

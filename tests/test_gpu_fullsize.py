@@ -180,6 +180,17 @@ def test_held_out_config3b_and_config5b():
     assert len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
 
 
+@pytest.mark.parametrize("cpfit", [False, True])
+def test_held_out_config4b(cpfit):
+    """Held-out instance of config 4 (no migration; 256 split values, a third of them fractional): every candidate within 1e-9 of the compiled baseline under both fits."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = workloads.config4b(lambda *a: truth_spectrum(*a), cpfit=cpfit)
+    idx = np.arange(w.n_cand)
+    rep = full_contract(w, idx)
+    assert rep["both"] == 256 and rep["tight"] == 256 and rep["worst_tight"] <= 1e-9 and len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
+
+
 def test_config5_sample_every_candidate():
     """BASELINE config 5 (ancient second genome, band x pulse x split): 4 096 of the 65 536 candidates, evenly spaced."""
     from misti_amd import workloads
