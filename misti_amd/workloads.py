@@ -68,10 +68,10 @@ def config1(spectrum_fn, n_sites=10 ** 6):
 
 
 def config2(spectrum_fn, n_split=64, n_rate=64, first_split=32, true_split=64, true_rate=0.2, n_sites=10 ** 6, max_rate=1.0, cpfit=True,
-            psmc_seeds=(1, 2), truth_seed=7):
+            psmc_seeds=(1, 2), truth_seed=7, psmc_rows=(64, 65)):
     """numT = 128; grid of split index x rate of one band ``-mi 1 4 {st} {r} 1``, ``--cpfit`` (``cpfit=False``: the
     reference's default fit, MiSTI.py:86,213)."""
-    inp = synth.psmc_pair(64, 65, seeds=psmc_seeds)
+    inp = synth.psmc_pair(psmc_rows[0], psmc_rows[1], seeds=psmc_seeds)
     band_truth = [(0, 4, true_split, true_rate, -1)]
     mis, pus = _mis_pus(band_truth, [], true_split)
     times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=truth_seed)
@@ -101,6 +101,20 @@ def config2c(spectrum_fn, cpfit=True):
     axis 36 ... 99): does what was learnt on config2b hold on data nobody has looked at?"""
     w = config2(spectrum_fn, first_split=36, true_split=60, true_rate=0.3, cpfit=cpfit, psmc_seeds=(5, 6), truth_seed=9)
     w.name = "config2c: second held-out instance of " + w.name
+    return w
+
+
+def config2n64(spectrum_fn, cpfit=True):
+    """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
+    w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))
+    w.name = "config2n64: held-out, numT=64: " + w.name
+    return w
+
+
+def config2n255(spectrum_fn, cpfit=True):
+    """Held-out instance at the largest grid: numT = 255 (two PSMC files of 128 rows, seeds 9, 10; true history seed 11; true split 120, rate 0.08), 64 splits x 64 rates."""
+    w = config2(spectrum_fn, first_split=70, true_split=120, true_rate=0.08, cpfit=cpfit, psmc_seeds=(9, 10), truth_seed=11, psmc_rows=(128, 128))
+    w.name = "config2n255: held-out, numT=255: " + w.name
     return w
 
 

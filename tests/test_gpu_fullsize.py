@@ -49,7 +49,7 @@ def studied(workload):
     """Candidates of `workload` that /root/reference itself was run on (candidate -> case)."""
     from conftest import load_golden
     out = {}
-    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b"):
+    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255"):
         if os.path.exists(os.path.join(GOLDEN, f + ".json")):
             for c in load_golden(f):
                 if c["fullsize"]["workload"] == workload:
@@ -178,6 +178,22 @@ def test_held_out_config3b_and_config5b():
     rep = full_contract(w, idx)
     check("config5b/32", "config5b", idx, rep)
     assert len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
+
+
+@pytest.mark.parametrize("name,stride", [("config2n64", 2), ("config2n255", 8)])
+@pytest.mark.parametrize("cpfit", [True, False])
+def test_held_out_other_grid_sizes(name, stride, cpfit):
+    """Held-out grids at numT = 64 and numT = 255 (the C ABI's largest), both fits, strided samples (the whole grids: tools/fullsize_report.py, profiles/r05_fullsize_contract_first_pass.txt):
+    nothing outside; status cases only where reference-studied (numT 255, default fit: one chain, the reference flips on all 30)."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = getattr(workloads, name)(lambda *a: truth_spectrum(*a), cpfit=cpfit)
+    idx = np.arange(5, w.n_cand, stride)
+    rep = full_contract(w, idx)
+    key = "%s%s/%d" % (name, "" if cpfit else ":default", stride)
+    MEASURED.setdefault(key, dict(both=None, tight=None, outside=0))
+    check(key, name + ("" if cpfit else ":default"), idx, rep)
+    assert len(rep["outside"]) == 0
 
 
 @pytest.mark.parametrize("cpfit", [False, True])

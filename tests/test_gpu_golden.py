@@ -22,6 +22,7 @@ CONFIG5_DEFAULT = load_golden("golden_config5_default_sample")
 CONFIG2B = load_golden("golden_config2b")
 CONFIG2C = load_golden("golden_config2c")
 CONFIG3B = load_golden("golden_config3b")
+CONFIG2N255 = load_golden("golden_config2n255")
 
 
 def run_case(case):
@@ -196,6 +197,14 @@ def test_held_out_config3b(case):
         except AssertionError:
             pytest.xfail("held-out two-way runaway candidate, %.3g relative: the reference's gain ratios there carry 0.03 - 0.04 of rounding error around the 0.75 threshold (profiles/r05_gain_ratio_config3b.txt)" % rel)
         return
+    check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG2N255, ids=[c["name"] for c in CONFIG2N255])
+def test_held_out_largest_grid_status_cases(case):
+    """Held-out grids at other sizes (workloads.config2n64 / config2n255: numT 64 and 255, other PSMC curves and histories): first passes clean under both fits (0 of 2 048 + 1 853 +
+    4 096 + 3 200 outside) except 30 status cases of ONE chain at numT = 255 under the default fit - the reference reports a failure in its base run and a value in its own perturbed
+    runs on every one of them (16 + 16 runs each), the device returns a value."""
     check(case)
 
 
