@@ -104,6 +104,14 @@ def config2c(spectrum_fn, cpfit=True):
     return w
 
 
+def config2t(spectrum_fn, cpfit=False):
+    """The held-out grid config2b with --trueEPS (MigrationInference.py:74, :325-326: no lambda-correction; the spectrum path alone at full size)."""
+    w = config2b(spectrum_fn, cpfit=False)
+    w.flags = dict(w.flags, true_eps=True)
+    w.name = "config2t: --trueEPS on " + w.name
+    return w
+
+
 def config2n64(spectrum_fn, cpfit=True):
     """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
     w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))

@@ -196,6 +196,15 @@ def test_held_out_other_grid_sizes(name, stride, cpfit):
     assert len(rep["outside"]) == 0
 
 
+def test_held_out_grid_true_eps():
+    """The held-out grid under --trueEPS (MigrationInference.py:74: no lambda-correction, the spectrum path alone): all 4 096 candidates within 1e-9 of the compiled baseline."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = workloads.config2t(lambda *a: truth_spectrum(*a))
+    rep = full_contract(w, np.arange(w.n_cand))
+    assert rep["both"] == 4096 and rep["tight"] == 4096 and rep["worst_tight"] <= 1e-10 and len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
+
+
 @pytest.mark.parametrize("cpfit", [False, True])
 def test_held_out_config4b(cpfit):
     """Held-out instance of config 4 (no migration; 256 split values, a third of them fractional): every candidate within 1e-9 of the compiled baseline under both fits."""
