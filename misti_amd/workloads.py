@@ -112,6 +112,14 @@ def config2t(spectrum_fn, cpfit=False):
     return w
 
 
+def config2u(spectrum_fn, cpfit=True):
+    """The held-out grid config2b with the UNFOLDED spectrum (--uf, MigrationInference.py:600-609: seven classes instead of four folded ones), no smoothing (--nosmooth)."""
+    w = config2b(spectrum_fn, cpfit=cpfit)
+    w.flags = dict(w.flags, unfolded=True, smooth=False)
+    w.name = "config2u: unfolded, no smoothing, on " + w.name
+    return w
+
+
 def config2n64(spectrum_fn, cpfit=True):
     """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
     w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))

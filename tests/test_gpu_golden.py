@@ -23,6 +23,7 @@ CONFIG2B = load_golden("golden_config2b")
 CONFIG2C = load_golden("golden_config2c")
 CONFIG3B = load_golden("golden_config3b")
 CONFIG2N255 = load_golden("golden_config2n255")
+CONFIG2U = load_golden("golden_config2u")
 
 
 def run_case(case):
@@ -205,6 +206,13 @@ def test_held_out_largest_grid_status_cases(case):
     """Held-out grids at other sizes (workloads.config2n64 / config2n255: numT 64 and 255, other PSMC curves and histories): first passes clean under both fits (0 of 2 048 + 1 853 +
     4 096 + 3 200 outside) except 30 status cases of ONE chain at numT = 255 under the default fit - the reference reports a failure in its base run and a value in its own perturbed
     runs on every one of them (16 + 16 runs each), the device returns a value."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG2U, ids=[c["name"] for c in CONFIG2U])
+def test_held_out_grid_unfolded_no_smoothing(case):
+    """The held-out grid with the UNFOLDED spectrum and without smoothing (workloads.config2u: --uf --nosmooth): default fit 0 of 3 429 outside in the first pass; --cpfit 13 flagged -
+    the chain that config2b flags as well - each at 1.00 x the reference's own spread (its perturbed runs reach the device's value)."""
     check(case)
 
 
