@@ -120,6 +120,25 @@ def config2u(spectrum_fn, cpfit=True):
     return w
 
 
+def config2m(spectrum_fn, cpfit=True):
+    """Held-out grid with the band in the OTHER direction (``-mi 2 6 {st} {r} 1``: population 2, from interval 6) on yet other data (PSMC seeds 11, 12; history seed 13;
+    true split 66, true rate 0.12)."""
+    inp = synth.psmc_pair(64, 65, seeds=(11, 12))
+    true_split, true_rate = 66, 0.12
+    band_truth = [(1, 6, true_split, true_rate, -1)]
+    mis, pus = _mis_pus(band_truth, [], true_split)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=13)
+    jafs = spectrum_fn(times, lh, true_split, band_truth, [], 0)
+    splits = np.arange(36, 100, dtype=np.float64)
+    rates = np.logspace(-3, 0, 64)
+    st, rr = np.meshgrid(splits, rates, indexing="ij")
+    w = Workload("config2m: held-out, numT=128, 64x64 split x mi-rate grid, one band into population 2, %s" % ("--cpfit" if cpfit else "default fit"),
+                 times, lh, [(1, 6, -1, 0.0, 0)], [], 1, dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
+                 st.ravel().copy(), rr.ravel()[:, None].copy(), dict(split=true_split, rate=true_rate))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, 10 ** 6)])
+    return w
+
+
 def config2n64(spectrum_fn, cpfit=True):
     """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
     w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))

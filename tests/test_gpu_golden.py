@@ -24,6 +24,7 @@ CONFIG2C = load_golden("golden_config2c")
 CONFIG3B = load_golden("golden_config3b")
 CONFIG2N255 = load_golden("golden_config2n255")
 CONFIG2U = load_golden("golden_config2u")
+CONFIG2M = load_golden("golden_config2m")
 
 
 def run_case(case):
@@ -213,6 +214,13 @@ def test_held_out_largest_grid_status_cases(case):
 def test_held_out_grid_unfolded_no_smoothing(case):
     """The held-out grid with the UNFOLDED spectrum and without smoothing (workloads.config2u: --uf --nosmooth): default fit 0 of 3 429 outside in the first pass; --cpfit 13 flagged -
     the chain that config2b flags as well - each at 1.00 x the reference's own spread (its perturbed runs reach the device's value)."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG2M, ids=[c["name"] for c in CONFIG2M])
+def test_held_out_grid_band_into_population_two(case):
+    """Held-out grid with the migration band in the other direction (workloads.config2m: `-mi 2 6 {st} {r} 1`, yet other PSMC curves and history): --cpfit 0 of 4 096 outside
+    (3 515 within 1e-9), default fit 0 of 3 264 outside and 12 status cases against the compiled baseline - on all 12 the REFERENCE has a value, the device within 0.00 ... 2.3 x its spread."""
     check(case)
 
 
