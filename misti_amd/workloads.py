@@ -139,6 +139,16 @@ def config2m(spectrum_fn, cpfit=True):
     return w
 
 
+def config2f(spectrum_fn, cpfit=True):
+    """The held-out grid config2b with FRACTIONAL split times (MigrationInference.py:89-99: the split inside an interval): the split axis 40.3, 41.05, 41.8, ... (step 0.75)."""
+    w = config2b(spectrum_fn, cpfit=cpfit)
+    n = w.n_cand // 64
+    splits = 40.3 + 0.75 * np.arange(n)
+    w.split_time = np.repeat(splits, 64)
+    w.name = "config2f: fractional split times on " + w.name
+    return w
+
+
 def config2n64(spectrum_fn, cpfit=True):
     """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
     w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))

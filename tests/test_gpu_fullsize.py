@@ -49,7 +49,7 @@ def studied(workload):
     """Candidates of `workload` that /root/reference itself was run on (candidate -> case)."""
     from conftest import load_golden
     out = {}
-    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m"):
+    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"):
         if os.path.exists(os.path.join(GOLDEN, f + ".json")):
             for c in load_golden(f):
                 if c["fullsize"]["workload"] == workload:

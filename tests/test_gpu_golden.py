@@ -25,6 +25,7 @@ CONFIG3B = load_golden("golden_config3b")
 CONFIG2N255 = load_golden("golden_config2n255")
 CONFIG2U = load_golden("golden_config2u")
 CONFIG2M = load_golden("golden_config2m")
+CONFIG2F = load_golden("golden_config2f")
 
 
 def run_case(case):
@@ -221,6 +222,13 @@ def test_held_out_grid_unfolded_no_smoothing(case):
 def test_held_out_grid_band_into_population_two(case):
     """Held-out grid with the migration band in the other direction (workloads.config2m: `-mi 2 6 {st} {r} 1`, yet other PSMC curves and history): --cpfit 0 of 4 096 outside
     (3 515 within 1e-9), default fit 0 of 3 264 outside and 12 status cases against the compiled baseline - on all 12 the REFERENCE has a value, the device within 0.00 ... 2.3 x its spread."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", CONFIG2F, ids=[c["name"] for c in CONFIG2F])
+def test_held_out_grid_fractional_splits(case):
+    """The held-out grid with FRACTIONAL split times (workloads.config2f: 40.3, 41.05, ... - the tail interval of every candidate): default fit 0 of 3 456 outside, no status
+    case; --cpfit 2 of 4 096 flagged (the chain config2b flags), each at <= 1.00 x the reference's own spread."""
     check(case)
 
 

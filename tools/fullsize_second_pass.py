@@ -22,7 +22,7 @@ from parity import SELF_FACTOR, internal_of, llk_bound, spread_of, status_flips_
 def main():
     dump = sys.argv[1]
     ref = {}
-    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m"):
+    for f in ("golden_fullsize", "golden_default_fit", "golden_default_fit_256", "golden_fullsize_r05", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"):
         for c in load_golden(f):
             ref[(c["fullsize"]["workload"], int(c["fullsize"]["cand"]))] = c
     print("# first pass: tools/fullsize_report.py (every candidate, compiled baseline as checker, 16 + 16 runs, factor %g) - %s/report.txt" % (SELF_FACTOR, dump))

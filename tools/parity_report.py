@@ -30,7 +30,7 @@ def main():
     worst_factor = worst_int = worst_wide = 0.0
     factors = []
     files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["golden_small", "golden_synthetic", "golden_sweep", "golden_campaign", "golden_fullsize", "golden_default_fit",
-                                                                    "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m"]
+                                                                    "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"]
     for f in files:
         for c in load_golden(f):
             o = c["out"]
