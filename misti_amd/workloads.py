@@ -149,6 +149,26 @@ def config2f(spectrum_fn, cpfit=True):
     return w
 
 
+def config2pu(spectrum_fn, cpfit=True):
+    """Held-out grid of a PULSE-only model (``-pu 2 30 {f} 1`` and a fixed band ``-mi 1 8 {st} 0.05``) on yet other data (PSMC seeds 13, 14; history seed 15; true split 72,
+    true pulse 0.2): 64 split values x 64 pulse fractions 0 ... 0.6."""
+    inp = synth.psmc_pair(64, 65, seeds=(13, 14))
+    true_split = 72
+    band_truth = [(0, 8, true_split, 0.05, -1)]
+    pulse_truth = [(1, 30, 0.2, -1)]
+    mis, pus = _mis_pus(band_truth, pulse_truth, true_split)
+    times, lh, _ = synth.self_consistent(inp, true_split, mis, pus, seed=15)
+    jafs = spectrum_fn(times, lh, true_split, band_truth, pulse_truth, 0)
+    splits = np.arange(40, 104, dtype=np.float64)
+    fr = np.linspace(0.0, 0.6, 64)
+    st, ff = np.meshgrid(splits, fr, indexing="ij")
+    w = Workload("config2pu: held-out, numT=128, 64x64 split x pulse-fraction grid, fixed band, %s" % ("--cpfit" if cpfit else "default fit"),
+                 times, lh, [(0, 8, -1, 0.05, -1)], [(1, 30, 0.0, 0)], 1, dict(cpfit=cpfit, true_eps=False, smooth=True, unfolded=False), 0,
+                 st.ravel().copy(), ff.ravel()[:, None].copy(), dict(split=true_split, pulse=0.2))
+    w.jsfs = np.array([synth.counts_from_spectrum(jafs, 10 ** 6)])
+    return w
+
+
 def config2n64(spectrum_fn, cpfit=True):
     """Held-out instance at another grid size: numT = 64 (PSMC files of 32 and 33 rows, seeds 7, 8; true history seed 10; true split 30, rate 0.15), 32 splits x 64 rates."""
     w = config2(spectrum_fn, n_split=32, first_split=16, true_split=30, true_rate=0.15, cpfit=cpfit, psmc_seeds=(7, 8), truth_seed=10, psmc_rows=(32, 33))

@@ -196,6 +196,17 @@ def test_held_out_other_grid_sizes(name, stride, cpfit):
     assert len(rep["outside"]) == 0
 
 
+@pytest.mark.parametrize("cpfit", [True, False])
+def test_held_out_pulse_grid(cpfit):
+    """Held-out grid of a pulse model (workloads.config2pu: split x pulse fraction, a fixed band), every eighth candidate: nothing outside, no status case (the whole grid: 4 096 / 4 050
+    candidates with a value on both sides, 0 / 0 outside - profiles/r05_fullsize_contract_first_pass.txt)."""
+    from misti_amd import workloads
+    from misti_amd.engine import truth_spectrum
+    w = workloads.config2pu(lambda *a: truth_spectrum(*a), cpfit=cpfit)
+    rep = full_contract(w, np.arange(1, w.n_cand, 8))
+    assert rep["both"] >= 500 and len(rep["outside"]) == 0 and len(rep["mismatch"]) == 0
+
+
 def test_held_out_grid_true_eps():
     """The held-out grid under --trueEPS (MigrationInference.py:74: no lambda-correction, the spectrum path alone): all 4 096 candidates within 1e-9 of the compiled baseline."""
     from misti_amd import workloads
