@@ -268,7 +268,10 @@ int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
  * same time (one persistent host thread per context) and gathers / scatters every candidate's rows straight from / into the
  * caller's buffers: the result is bit for bit that of misti_eval_batch on one device.  Same arguments and conventions as
  * misti_eval_batch.  A failure on any context - a C++ exception in its worker thread included - fails the call with that
- * context's message; it never terminates the process. */
+ * context's message; it never terminates the process.
+ * Threading: like a misti_ctx, a misti_multi is used by ONE host thread at a time - its worker dispatch, shards and "last" records are
+ * per object.  The evaluating entry points take a per-object lock, so two threads calling into one object are serialised, never
+ * interleaved; callers that want concurrent batches create one object per thread.  misti_destroy_multi must not race a call. */
 typedef struct misti_multi misti_multi;
 int misti_create_multi(const misti_model_t* model, int n_dev, const int* devices, misti_multi** out);
 int misti_destroy_multi(misti_multi* m);

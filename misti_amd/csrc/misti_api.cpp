@@ -100,6 +100,7 @@ struct misti_ctx {
     DevBuf ws_chain_f64, ws_chain_i32;  // chain buffers (kernel 1 -> kernel 2) and the chain table
     DevBuf st_split, st_params, st_bounds, st_jsfs, st_llk, st_jafs, st_lc, st_pr, st_status;   // staging for the host-buffer form
     PinBuf pin_in, pin_out;             // pinned staging of misti_eval_batch: inputs packed, outputs packed
+    std::vector<char> heap_in, heap_out;   // pageable staging of the indexed form beyond PIN_STAGE_MAX (kept here: they outlive an error return's drain)
     bool trace = false;                 // solver trace (misti_enable_solver_trace)
     DevBuf ws_solver, ws_iters;         // per chain / per candidate solver words; trial points of small batches
     DevBuf ws_post;                     // default fit: rates after the split per candidate and interval (+ their solver words)
@@ -269,8 +270,8 @@ int record_end(misti_ctx* c, int which, hipEvent_t a, hipEvent_t b) {
 //   RUN_UNSHARED        every candidate has its own parameter vector: no trunk for a batch too large for one chain per wave
 //   RUN_ONE_LENGTH      every chain has the same number of intervals: the chains need no sorting by length
 enum : unsigned { RUN_INTEGER_SPLITS = 1u, RUN_UNSHARED = 2u, RUN_ONE_LENGTH = 4u };
-int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
-            double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, unsigned hints = 0) {
+int run_dev_impl(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
+                 double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, unsigned hints) {
     if (n_cand < 0 || n_rep < 0) return fail(MISTI_E_ARG, "negative batch size");
     if (n_cand == 0) return 0;
     if (!d_split) return fail(MISTI_E_ARG, "split_time is NULL");
@@ -474,6 +475,22 @@ int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d
     return 0;
 }
 
+// A two-phase batch joins its side stream to the batch's stream with its LAST wait; a failure anywhere between the phase-1 launch and
+// that wait would return with phase-1 kernels in flight on a stream nothing else waits for (misti_sync and the host-buffer drain
+// know the batch's stream) while the next batch's set-up rewrites the chain buffers they read.  So: on any failure the side stream is
+// drained before the error is reported.
+int run_dev(misti_ctx* c, int64_t n_cand, const double* d_split, const double* d_params, const int32_t* d_bounds, int64_t n_rep, const double* d_jsfs,
+            double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, unsigned hints = 0) {
+    const int r = run_dev_impl(c, n_cand, d_split, d_params, d_bounds, n_rep, d_jsfs, d_llk, d_jafs, d_lc, d_pr, d_status, hints);
+    if (r != 0 && c->side_stream) {
+        const std::string why = g_err;
+        (void)hipStreamSynchronize(c->side_stream);
+        (void)hipGetLastError();
+        g_err = why;
+    }
+    return r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -649,24 +666,27 @@ int misti_destroy(misti_ctx* c) {
         for (size_t i = 0; i < g_ctxs.size(); ++i) if (g_ctxs[i] == c) { g_ctxs.erase(g_ctxs.begin() + (long)i); break; }
     }
     (void)hipSetDevice(c->device);
+    // EVERYTHING the context ever issued is finished before anything it owns is released: the stream batches are issued on (the
+    // caller's, after misti_set_stream), the context's own stream (work issued before a misti_set_stream is ordered before its
+    // successor by an event, which this wait does not rely on) and the side stream of two-phase batches.  Only then buffers, the
+    // mapped hint word the set-up kernel writes, events, and last the streams themselves.
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->own_stream != c->stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
+    (void)hipGetLastError();
     for (auto* b : {&c->model_f64, &c->model_i32, &c->consts, &c->ws_jafs, &c->ws_status, &c->ws_chain_f64, &c->ws_chain_i32, &c->ws_order, &c->ws_diag, &c->ws_trunk, &c->ws_solver, &c->ws_iters, &c->ws_post,
-                    &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status})
+                    &c->st_split, &c->st_params, &c->st_bounds, &c->st_jsfs, &c->st_llk, &c->st_jafs, &c->st_lc, &c->st_pr, &c->st_status, &c->nm_f64, &c->nm_i32})
         b->release();
-    if (c->order_ev) (void)hipEventDestroy(c->order_ev);
-    if (c->last_ev) (void)hipEventDestroy(c->last_ev);
     c->pin_in.release();
     c->pin_out.release();
-    c->nm_f64.release();
-    c->nm_i32.release();
     if (c->nm_live_host) (void)hipHostFree(c->nm_live_host);
+    if (c->hint_host) (void)hipHostFree(c->hint_host);
     for (int w = 0; w < 3; ++w)
         for (auto& pr : c->pending[w]) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : {c->order_ev, c->last_ev, c->packed_ev, c->side_ev}) if (e) (void)hipEventDestroy(e);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
-    if (c->hint_host) (void)hipHostFree(c->hint_host);
-    if (c->side_stream) { (void)hipStreamSynchronize(c->side_stream); (void)hipStreamDestroy(c->side_stream); }
-    if (c->packed_ev) (void)hipEventDestroy(c->packed_ev);
-    if (c->side_ev) (void)hipEventDestroy(c->side_ev);
+    (void)hipGetLastError();
     delete c;
     return 0;
 }
@@ -703,6 +723,7 @@ int misti_sync(misti_ctx* c) {
     if (!c) return fail(MISTI_E_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->side_stream) HIP_TRY(hipStreamSynchronize(c->side_stream));      // joined to the stream by every batch that used it; a failed one may not have got that far
     return 0;
 }
 
@@ -751,6 +772,7 @@ int eval_batch_drained(misti_ctx* c, int r) {
         const std::string why = g_err;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
         (void)hipGetLastError();
         g_err = why;
     }
@@ -809,7 +831,10 @@ int eval_batch_host(misti_ctx* c, int64_t n_cand, const double* split, const dou
     if (!pinned) (void)hipGetLastError();
     // Indexed form (idx: rows of the caller's arrays, misti_eval_batch_indexed_): rows are gathered on the way in and scattered on the
     // way out; beyond the pinned block's limit the gather goes through pageable heap blocks (std::bad_alloc is the caller's to catch).
-    std::vector<char> heap_in, heap_out;
+    // They belong to the context: an error return leaves copies in flight until misti_eval_batch's drain, which comes AFTER this
+    // function's locals are gone.
+    std::vector<char>& heap_in = c->heap_in;
+    std::vector<char>& heap_out = c->heap_out;
     if (idx && !pinned) { heap_in.resize(in_bytes); heap_out.resize(out_bytes ? out_bytes : 8); }
     char* hin = pinned ? static_cast<char*>(c->pin_in.p) : (idx ? heap_in.data() : nullptr);
     const bool staged = pinned || idx;

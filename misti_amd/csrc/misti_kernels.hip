@@ -3124,11 +3124,13 @@ static size_t trunk_lds_bytes(int numT) { return (128 + 2 * (size_t)(numT + 1)) 
 
 template <bool CPFIT, int GROUP>
 static void launch_chains_t(const DevModel& m, int64_t n_items, const ChainBufs& cb, const double* split, const double* params, int yield_nfev,
-                            hipStream_t stream, hipEvent_t after_packed) {
+                            hipStream_t stream, hipEvent_t after_packed, hipError_t& event_error) {
     const int per_wave = 64 / GROUP;
     dim3 grid((unsigned)((n_items + per_wave - 1) / per_wave));
     hipLaunchKernelGGL((correct_kernel<CPFIT, GROUP>), grid, dim3(64), correct_lds_bytes(m.numT), stream, m, n_items, cb, split, params, yield_nfev);
-    if (after_packed) (void)hipEventRecord(after_packed, stream);             // phase 1 of what follows the chains starts here, beside the resume launch
+    // phase 1 of what follows the chains starts here, beside the resume launch.  A record that fails must fail the batch: the side
+    // stream's wait on a never-recorded (or stale) event is a no-op, and phase 1 would race this launch.
+    if (after_packed) event_error = hipEventRecord(after_packed, stream);
     if (yield_nfev > 0 && GROUP != 64) {
         // the chains that yielded, one per wave: as many workgroups as are resident (two waves per SIMD for --cpfit, one for the
         // default fit); those beyond the list's length leave at once
@@ -3185,10 +3187,14 @@ hipError_t launch_correct(const DevModel& m, int64_t n_cand, const ChainBufs& cb
         if (blocks < floor_blocks) blocks = floor_blocks;
         if (cp) hipLaunchKernelGGL(correct_follow_kernel<true>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
         else hipLaunchKernelGGL(correct_follow_kernel<false>, dim3((unsigned)blocks), dim3(128), lds, stream, m, n_cand, cb, split, params);
-        return hipGetLastError();
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && after_packed) e = hipEventRecord(after_packed, stream);      // never left unrecorded for a caller that waits on it
+        return e;
     }
-    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, yield_nfev, stream, after_packed)
-    return hipGetLastError();
+    hipError_t event_error = hipSuccess;
+    MISTI_DISPATCH_GROUP(launch_chains_t, m, n_cand, cb, split, params, yield_nfev, stream, after_packed, event_error)
+    const hipError_t e = hipGetLastError();
+    return e != hipSuccess ? e : event_error;
 }
 
 // chains the trunk buffer must hold for a batch of n_cand (the trunk runs only when

@@ -119,7 +119,11 @@ struct misti_multi {
     std::vector<double> last_cost;                       // ... and the summed chain cost per context (what the dealing balances)
     std::vector<std::vector<int64_t>> shard;             // candidate rows per context (kept between calls: no allocation in steady state)
     std::vector<void*> comm;                             // RCCL communicators, one per context (created by the first _dev call)
-    int throw_in_worker = -1;                            // test hook (MISTI_MULTI_THROW_IN_WORKER, read once in misti_create_multi)
+    int throw_in_worker = -1;                            // test hook: context whose worker body throws (misti_multi_test_throw_in_worker_, below)
+    // One call at a time per object: the dispatch state below (job, pending, generation, rc, msg), the shards and the last_* records
+    // are per object.  Two caller threads on ONE misti_multi are serialised here (include/misti_hip.h says so); callers that want
+    // concurrency use one object per thread, as with misti_ctx.
+    std::mutex call_mu;
 
     // persistent workers: thread d serves context d
     std::vector<std::thread> th;
@@ -300,7 +304,6 @@ int misti_create_multi(const misti_model_t* model, int n_dev, const int* devices
         m->shard.resize(n_dev);
         m->rc.assign(n_dev, 0);
         m->msg.resize(n_dev);
-        if (const char* e = std::getenv("MISTI_MULTI_THROW_IN_WORKER")) m->throw_in_worker = std::atoi(e);   // tests: a worker that throws must fail the call, not the process
         if (n_dev > 1) {
             m->th.reserve(n_dev);
             for (int d = 0; d < n_dev; ++d) m->th.emplace_back([m, d] { m->worker(d); });     // a failure here joins the threads already started (below)
@@ -332,6 +335,17 @@ int misti_destroy_multi(misti_multi* m) {
     for (misti_ctx* c : m->ctx) { const int r = misti_destroy(c); if (r != 0 && rc == 0) rc = r; }
     delete m;
     return rc;
+}
+
+// TEST HOOK, not part of the public ABI (no declaration in include/misti_hip.h, trailing underscore like misti_eval_batch_indexed_): from
+// now on the worker body of context `d` throws a C++ exception (d < 0: never) - tests/test_gpu_multi.py checks that such a call fails
+// with an error code and message while the process, the workers and later calls live on.  Nothing in the library reads the environment
+// for it any more (a set variable made every multi call of a production process fail).
+int misti_multi_test_throw_in_worker_(misti_multi* m, int d) {
+    if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
+    m->throw_in_worker = d;
+    return 0;
 }
 
 int misti_multi_size(misti_multi* m) { return m ? (int)m->ctx.size() : 0; }
@@ -371,6 +385,7 @@ int misti_multi_eval_batch(misti_multi* m, int64_t n_cand, const double* split, 
                            int64_t n_rep, const double* jsfs, double* llk, double* jafs, double* lc, double* pr, int32_t* status) {
     if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
     if (n_cand < 0 || n_rep < 0) return failm(MISTI_E_ARG, "negative batch size");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     const int D = (int)m->ctx.size();
     for (int d = 0; d < D; ++d) { m->last_cands[d] = m->last_chains[d] = 0; m->last_cost[d] = 0.0; }
     if (n_cand == 0) return 0;
@@ -385,7 +400,7 @@ int misti_multi_eval_batch(misti_multi* m, int64_t n_cand, const double* split, 
     return guarded("misti_multi_eval_batch", [&]() -> int {
         deal_chains(m, n_cand, split, params, band_bounds);
         const std::function<int(int)> fn = [&](int d) -> int {
-            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            if (d == m->throw_in_worker) throw std::runtime_error("misti_multi_test_throw_in_worker_");
             const std::vector<int64_t>& idx = m->shard[d];
             if (idx.empty()) return 0;
             // rows idx[] of the caller's arrays: gathered into / scattered from the context's pinned block (disjoint rows: no two threads share one)
@@ -403,6 +418,7 @@ int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t ro
     if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
     if (!n_cand || !d_split_time || !d_llk_all || !d_jsfs) return failm(MISTI_E_ARG, "n_cand / d_split_time / d_jsfs / d_llk_all is NULL");
     if (n_rep < 1) return failm(MISTI_E_ARG, "the gathered form needs at least one replicate");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     const int D = (int)m->ctx.size(), P = m->n_param;
     if (P > 0 && !d_params) return failm(MISTI_E_ARG, "d_params is NULL but the model has %d parameters", P);
     for (int d = 0; d < D; ++d) {
@@ -427,7 +443,7 @@ int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t ro
         // every context issues its batch at the same time (a launch sequence costs the host ~50 us per batch): context d writes its
         // rows straight into block d of ITS gathered table, the rows beyond its shard are NaN (all-ones bytes)
         const std::function<int(int)> fn = [&](int d) -> int {
-            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            if (d == m->throw_in_worker) throw std::runtime_error("misti_multi_test_throw_in_worker_");
             void* sv = nullptr;
             if (int q = misti_get_stream(m->ctx[d], &sv)) return q;
             hipStream_t s = static_cast<hipStream_t>(sv);
@@ -474,11 +490,12 @@ int misti_multi_nm_solve(misti_multi* m, int64_t n_start, const double* starts, 
     if (n_start < 0) return failm(MISTI_E_ARG, "negative number of starts");
     if (n_start == 0) return 0;
     if (!starts || !jsfs_row || !x || !llh) return failm(MISTI_E_ARG, "starts / jsfs_row / x / llh is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     return guarded("misti_multi_nm_solve", [&]() -> int {
         const int D = (int)m->ctx.size(), N = m->n_param;
         const std::vector<int64_t> lo = blocks(n_start, D);
         const std::function<int(int)> fn = [&](int d) -> int {
-            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            if (d == m->throw_in_worker) throw std::runtime_error("misti_multi_test_throw_in_worker_");
             const int64_t a = lo[d], n = lo[d + 1] - lo[d];
             if (n == 0) return 0;
             return misti_nm_solve(m->ctx[d], n, starts + a * N, split_time, jsfs_row, xatol, fatol, maxiter, x + a * N, llh + a,
@@ -496,12 +513,13 @@ int misti_multi_basinhopping(misti_multi* m, int64_t n_start, const double* star
     if (n_start < 0 || niter < 0) return failm(MISTI_E_ARG, "negative number of starts / hops");
     if (n_start == 0) return 0;
     if (!starts || !jsfs_row || !x || !llh || (niter > 0 && !uniforms)) return failm(MISTI_E_ARG, "starts / jsfs_row / uniforms / x / llh is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     return guarded("misti_multi_basinhopping", [&]() -> int {
         const int D = (int)m->ctx.size(), N = m->n_param;
         const std::vector<int64_t> lo = blocks(n_start, D);
         const int64_t per_start = (int64_t)niter * (N + 1);
         const std::function<int(int)> fn = [&](int d) -> int {
-            if (d == m->throw_in_worker) throw std::runtime_error("MISTI_MULTI_THROW_IN_WORKER");
+            if (d == m->throw_in_worker) throw std::runtime_error("misti_multi_test_throw_in_worker_");
             const int64_t a = lo[d], n = lo[d + 1] - lo[d];
             if (n == 0) return 0;
             return misti_basinhopping(m->ctx[d], n, starts + a * N, split_time, jsfs_row, niter, T, stepsize, interval, target_accept_rate, stepwise_factor,

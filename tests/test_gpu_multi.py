@@ -184,22 +184,26 @@ def test_gather_inside_the_library_on_a_one_device_communicator():
             m2.evaluate_dev_gathered([n, 0], per, [d_split.data_ptr()] * 2, [d_par.data_ptr()] * 2, R, [d_jsfs.data_ptr()] * 2, [d_all.data_ptr()] * 2)
 
 
-def test_an_exception_in_a_worker_thread_fails_the_call_not_the_process(grid, monkeypatch):
-    """include/misti_hip.h: no C++ exception crosses the ABI.  A worker thread that throws (test hook MISTI_MULTI_THROW_IN_WORKER,
-    read once in misti_create_multi) makes the call return MISTI_E_ARG with the context's message; the persistent workers survive
-    and the next call on another object still works."""
+def test_an_exception_in_a_worker_thread_fails_the_call_not_the_process(grid):
+    """include/misti_hip.h: no C++ exception crosses the ABI.  A worker thread that throws (internal test hook
+    misti_multi_test_throw_in_worker_: not in the public header, nothing in the library reads the environment for it) makes the call
+    return MISTI_E_ARG with the context's message; the persistent workers survive, and with the hook cleared the SAME object works."""
+    import ctypes as C
     from misti_amd._lib import MistiError
     from misti_amd.engine import MultiEngine
     w = grid
-    monkeypatch.setenv("MISTI_MULTI_THROW_IN_WORKER", "1")
     with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m:
+        want = m.evaluate(w.split_time, w.params, w.jsfs)
+        hook = m._lib.misti_multi_test_throw_in_worker_
+        hook.restype, hook.argtypes = C.c_int, [C.c_void_p, C.c_int]
+        assert hook(m._m, 1) == 0
         for _ in range(2):
-            with pytest.raises(MistiError, match=r"context 1 of 2.*MISTI_MULTI_THROW_IN_WORKER") as ei:
+            with pytest.raises(MistiError, match=r"context 1 of 2.*misti_multi_test_throw_in_worker_") as ei:
                 m.evaluate(w.split_time, w.params, w.jsfs)
             assert ei.value.code == -1
-    monkeypatch.delenv("MISTI_MULTI_THROW_IN_WORKER")
-    with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m:
-        assert np.isfinite(m.evaluate(w.split_time, w.params, w.jsfs).llk).any()
+        assert hook(m._m, -1) == 0
+        got = m.evaluate(w.split_time, w.params, w.jsfs)
+        assert np.array_equal(got.llk, want.llk, equal_nan=True) and np.array_equal(got.status, want.status)
 
 
 def test_c_example_gathered_on_the_devices(tmp_path):
