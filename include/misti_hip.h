@@ -297,7 +297,8 @@ int misti_multi_last_cost(misti_multi* m, double* cost);
  *   d_llk_all       [D]   device i's table [D][rows_per_shard][n_rep]: block r = shard r's rows, rows beyond n_cand[r] NaN
  *   d_status_all    [D] or NULL   device i's table [D][rows_per_shard] of per-candidate status (-1 beyond n_cand[r])
  * Asynchronous: returns when everything is issued; misti_multi_sync waits for every context's stream.  librccl.so.1 is bound
- * at the first call (dlopen by soname: a process that already maps an RCCL - PyTorch-ROCm does - uses that copy). */
+ * at the first call (dlopen by soname: a process that already maps an RCCL - PyTorch-ROCm does - uses that copy; MISTI_RCCL_LIB=<path>
+ * in the environment names another build to bind instead - read once, at the first gathered call of the process). */
 int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t rows_per_shard,
                                const double* const* d_split_time, const double* const* d_params, const int32_t* const* d_band_bounds,
                                int64_t n_rep, const double* const* d_jsfs, double* const* d_llk_all, int32_t* const* d_status_all);

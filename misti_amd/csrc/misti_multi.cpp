@@ -17,6 +17,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -80,6 +81,7 @@ struct Rccl {
     int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    bool test_double = false;       // the loaded library exports `misti_test_rccl_double` (tests/multi_host/fake_rccl.cpp): copies inside one process
     std::string why;
 };
 constexpr int NCCL_INT32 = 2, NCCL_FLOAT64 = 8;
@@ -88,11 +90,20 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.handle) break;
+        // MISTI_RCCL_LIB=<path>: the RCCL build to bind instead of the process's / the system's (a site's own build - or the tests' double,
+        // which lets the gathered form run with several contexts on one GPU); read once, at the first gathered call of the process
+        const char* chosen = std::getenv("MISTI_RCCL_LIB");
+        if (chosen && chosen[0]) {
+            r.handle = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) { const char* e = dlerror(); r.why = std::string("MISTI_RCCL_LIB=") + chosen + " cannot be loaded: " + (e ? e : "?"); return; }
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.handle) break;
+            }
+            if (!r.handle) { const char* e = dlerror(); r.why = std::string("librccl.so.1 cannot be loaded: ") + (e ? e : "?"); return; }
         }
-        if (!r.handle) { const char* e = dlerror(); r.why = std::string("librccl.so.1 cannot be loaded: ") + (e ? e : "?"); return; }
+        r.test_double = dlsym(r.handle, "misti_test_rccl_double") != nullptr;
         auto sym = [&](const char* n) -> void* {
             void* p = dlsym(r.handle, n);
             if (!p && r.why.empty()) r.why = std::string("RCCL lacks ") + n;
@@ -359,6 +370,7 @@ int misti_multi_context(misti_multi* m, int i, misti_ctx** ctx, int* device) {
 
 int misti_multi_last_shards(misti_multi* m, int64_t* n_cand, int64_t* n_chain) {
     if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     for (size_t d = 0; d < m->ctx.size(); ++d) {
         if (n_cand) n_cand[d] = m->last_cands[d];
         if (n_chain) n_chain[d] = m->last_chains[d];
@@ -368,12 +380,14 @@ int misti_multi_last_shards(misti_multi* m, int64_t* n_cand, int64_t* n_chain) {
 
 int misti_multi_last_cost(misti_multi* m, double* cost) {
     if (!m || !cost) return failm(MISTI_E_ARG, "multi context / cost is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     for (size_t d = 0; d < m->ctx.size(); ++d) cost[d] = m->last_cost[d];
     return 0;
 }
 
 int misti_multi_sync(misti_multi* m) {
     if (!m) return failm(MISTI_E_ARG, "multi context is NULL");
+    std::lock_guard<std::mutex> one_call(m->call_mu);
     for (size_t d = 0; d < m->ctx.size(); ++d) {
         const int r = misti_sync(m->ctx[d]);
         if (r != 0) { const std::string why = misti_last_error(); return failm(r, "device %d (context %d): %s", m->device[d], (int)d, why.c_str()); }
@@ -421,12 +435,20 @@ int misti_multi_eval_batch_dev(misti_multi* m, const int64_t* n_cand, int64_t ro
     std::lock_guard<std::mutex> one_call(m->call_mu);
     const int D = (int)m->ctx.size(), P = m->n_param;
     if (P > 0 && !d_params) return failm(MISTI_E_ARG, "d_params is NULL but the model has %d parameters", P);
+    bool repeated = false;
     for (int d = 0; d < D; ++d) {
         if (n_cand[d] < 0 || n_cand[d] > rows_per_shard) return failm(MISTI_E_ARG, "shard %d: %lld candidates do not fit rows_per_shard = %lld", d, (long long)n_cand[d], (long long)rows_per_shard);
         if (!d_llk_all[d] || !d_jsfs[d] || (n_cand[d] > 0 && (!d_split_time[d] || (P > 0 && !d_params[d])))) return failm(MISTI_E_ARG, "shard %d: a device pointer is NULL", d);
         if (d_status_all && !d_status_all[d]) return failm(MISTI_E_ARG, "shard %d: d_status_all is NULL", d);
-        for (int e = 0; e < d; ++e)
-            if (m->device[e] == m->device[d]) return failm(MISTI_E_ARG, "device %d is listed twice: an RCCL communicator holds every device once", m->device[d]);
+        for (int e = 0; e < d; ++e) if (m->device[e] == m->device[d]) repeated = true;
+    }
+    // an RCCL communicator holds every device once (ncclCommInitAll refuses a repeated entry); only the tests' double, which copies
+    // inside the process, takes several contexts on one device
+    if (repeated) {
+        Rccl* R = rccl();
+        if (!R->test_double)
+            for (int d = 0; d < D; ++d) for (int e = 0; e < d; ++e)
+                if (m->device[e] == m->device[d]) return failm(MISTI_E_ARG, "device %d is listed twice: an RCCL communicator holds every device once", m->device[d]);
     }
     if (rows_per_shard == 0) return 0;
     return guarded("misti_multi_eval_batch_dev", [&]() -> int {

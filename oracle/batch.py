@@ -66,6 +66,36 @@ def _worker(args):
     return out, time.perf_counter() - t0
 
 
+def _children(jobs):
+    """_worker(job) for every job, each in a CHILD INTERPRETER started with subprocess (`python -m oracle.batch`), job and result
+    pickled over its pipes.  Never a fork: the caller may be a process with a live ROCm runtime (the -m gpu tests), whose forked
+    children would inherit the runtime's locks and mapped queues (bench.py starts its baseline as a fresh child for the
+    same reason) - and, unlike multiprocessing's "spawn", nothing here depends on the caller's __main__ being importable."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import threading
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), PYTHONDONTWRITEBYTECODE="1")
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.batch"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, cwd=root, env=env) for _ in jobs]
+    out = [None] * len(jobs)
+
+    def talk(k):                           # one thread per child: communicate() feeds stdin and drains stdout without deadlock
+        data, _ = procs[k].communicate(pickle.dumps(jobs[k]))
+        out[k] = data
+
+    threads = [threading.Thread(target=talk, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, p in enumerate(procs):
+        if p.returncode != 0:
+            raise RuntimeError("oracle child %d exited with status %s" % (k, p.returncode))
+    return [pickle.loads(o) for o in out]
+
+
 def oracle_batch(workload, indices, processes=1):
     """Oracle on a subset of a Workload's candidates.
 
@@ -80,11 +110,7 @@ def oracle_batch(workload, indices, processes=1):
         res = [_worker((common, cands))]
     else:
         chunks = [cands[k::processes] for k in range(processes)]
-        # The caller may hold GPU objects (engine contexts, device tensors): a forked child must never finalise its copies of
-        # them - HIP is unusable there - so the workers run without the cyclic collector (they live for one map() call).
-        import gc
-        with mp.get_context("fork").Pool(processes, initializer=gc.disable) as pool:
-            res = pool.map(_worker, [(common, c) for c in chunks])
+        res = _children([(common, c) for c in chunks])
         # undo the striding
         merged = [None] * len(cands)
         for k, (out, _) in enumerate(res):
@@ -98,3 +124,12 @@ def oracle_batch(workload, indices, processes=1):
     oracle_batch.last_runaway = np.array([o[3] for o in out])
     oracle_batch.last_jafs = [o[1] for o in out]
     return llk, status, wall
+
+
+if __name__ == "__main__":                 # a child of _children(): one pickled job on stdin, its pickled result on stdout
+    import pickle
+    import sys
+    job = pickle.load(sys.stdin.buffer)
+    result = _worker(job)
+    sys.stdout.buffer.write(pickle.dumps(result))
+    sys.stdout.buffer.flush()

@@ -1,6 +1,8 @@
 """The multi-device form of the C ABI (misti_create_multi ...: SURVEY 8b's "variant taking a device list") on the one GPU of the
 test box: the device list names device 0 two or three times, so the sharding - whole chains per context, one host thread each,
 rows scattered into the caller's buffers - runs for real, and every output must equal the single-context call bit for bit."""
+import os
+
 import numpy as np
 import pytest
 
@@ -182,6 +184,28 @@ def test_gather_inside_the_library_on_a_one_device_communicator():
     with MultiEngine(w.times, w.lh, devices=(0, 0), **w.engine_kwargs()) as m2:
         with pytest.raises(MistiError, match="listed twice"):
             m2.evaluate_dev_gathered([n, 0], per, [d_split.data_ptr()] * 2, [d_par.data_ptr()] * 2, R, [d_jsfs.data_ptr()] * 2, [d_all.data_ptr()] * 2)
+
+
+def test_gathered_form_on_three_contexts_through_the_rccl_double(tmp_path):
+    """misti_multi_eval_batch_dev with D > 1 before a multi-GPU node ever runs it.  tests/multi_host/fake_rccl.cpp (built
+    here with hipcc; it copies between the ranks' tables on their streams, ordered by events) is bound through MISTI_RCCL_LIB in a child
+    process, and the device list {0, 0, 0} runs three contexts, three persistent workers and ONE grouped ncclAllGather over three
+    communicators: ragged and empty shards, NaN / -1 padding, every context's table equal to one context's misti_eval_batch bit for bit,
+    a worker that throws.  Real RCCL over xGMI with D > 1 stays unmeasured on hardware."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    double = str(tmp_path / "libfake_rccl_hip.so")
+    subprocess.run([hipcc, "-O1", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950",
+                    os.path.join(ROOT, "tests", "multi_host", "fake_rccl.cpp"), "-o", double], check=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_host", "gather_double_check.py")], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MISTI_RCCL_LIB=double))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = dict(l.split(" = ") for l in r.stdout.splitlines() if " = " in l)
+    assert out["identical"] == "1" and out["throw"] == "reported", r.stdout
+    assert int(out["rounds"]) == 5 and int(out["collectives"]) == 2 * 2 * 5 and int(out["finite"]) > 100, r.stdout   # llk + status, twice per layout
 
 
 def test_an_exception_in_a_worker_thread_fails_the_call_not_the_process(grid):
