@@ -189,6 +189,87 @@ def llk_bound(ref_llk, row, jafs, unfolded, spread, internal=None, wide=None):
     return best
 
 
+# ---- clause 2 is mode-aware ---------------------------------------------------------------------------------
+# `spread` is a max over the reference's runs, and where the reference's runs are BIMODAL - one solve of the chain ends a step earlier or
+# later in a few of its runs, and the llh jumps by 1e-6 - "within 1.00 x the spread" admits a value on the branch the reference takes in 3 of
+# its 64 runs as readily as one on the branch it takes in 61.  A single candidate on a minority branch is one more sample of the reference's
+# own coin; MANY of them, or a device that sits on minority branches more often than the reference's own runs do, is a systematic
+# accept / reject difference.  So every golden case that holds the reference's run lists is classified:
+#   modes_of   the reference's runs (base + pert_llh + internal_llh + residual_llh) clustered: values within MODE_RTOL of a neighbour chain together
+#   branch_of  which cluster the device's value lies on, and the share of the reference's runs on it
+# and tests/test_gpu_golden.py::test_branch_rates_match_the_reference holds the NUMBER OF CHAINS on which the device is on a minority branch
+# to the reference's own minority rates (Poisson-binomial tail >= BRANCH_ALPHA).  Chains, not candidates: every member of a chain behind
+# the solve that flips inherits the flip (config2b / 2u / 2f share one chain: same PSMC data, same band, same rate).
+MODE_RTOL = 3e-9           # runs closer than this (relative) are the same branch: 3 x the tolerance of clause 1
+BRANCH_ALPHA = 0.05
+
+
+def reference_runs(out):
+    """Every llh the reference itself produced for this case: the base run and the perturbed runs the fixture holds."""
+    runs = [out["llh"]] if out.get("llh") is not None else []
+    for key in ("pert_llh", "internal_llh", "residual_llh"):
+        runs += [v for v in (out.get(key) or []) if v is not None]
+    return runs
+
+
+def modes_of(values, rtol=MODE_RTOL):
+    """Clusters (sorted lists) of the values: single linkage, neighbours within rtol (relative) belong together; largest cluster first."""
+    vals = sorted(float(v) for v in values)
+    if not vals:
+        return []
+    clusters = [[vals[0]]]
+    for v in vals[1:]:
+        if abs(v - clusters[-1][-1]) <= rtol * max(abs(v), 1e-300):
+            clusters[-1].append(v)
+        else:
+            clusters.append([v])
+    return sorted(clusters, key=lambda c: (-len(c), c[0]))
+
+
+def branch_of(out, llk):
+    """Where the value `llk` stands among the reference's own runs of this case.
+    Returns dict(runs, n_modes, mode (index into modes_of, 0 = the majority; None = on no branch of the reference), share (of the reference's runs
+    on that branch; 0.0 for None), majority_share) - or None when the fixture holds no run lists (nothing to classify)."""
+    runs = reference_runs(out)
+    if len(runs) < 8:
+        return None
+    modes = modes_of(runs)
+    n = float(len(runs))
+    where = None
+    for k, c in enumerate(modes):
+        pad = max(MODE_RTOL * abs(llk), c[-1] - c[0])
+        if c[0] - pad <= llk <= c[-1] + pad:
+            where = k
+            break
+    return dict(runs=len(runs), n_modes=len(modes), mode=where, share=0.0 if where is None else len(modes[where]) / n, majority_share=len(modes[0]) / n)
+
+
+def chain_key(case):
+    """What identifies a lambda-correction CHAIN across golden cases: the PSMC data, the fit, the bands / pulses without the split they end at, and
+    the parameter vector.  Cases that differ only in split time, spectrum folding or smoothing share their chain up to the shorter split."""
+    import hashlib
+    i = case["in"]
+    h = hashlib.sha256()
+    h.update(repr(([float(t) for t in i["times"]][:8], [[float(a), float(b)] for a, b in i["lambdas"]][:8])).encode())
+    bands = [(b[0], b[1], float(b[3]), b[4]) for b in i["mi"]]
+    pulses = [(q[0], q[1], float(q[2]), q[3]) for q in i["pu"]]
+    h.update(repr((bands, pulses, [float(v) for v in i["params"]], bool(i["kw"].get("cpfit")), bool(i["kw"].get("trueEPS")), i["kw"].get("sampleDate", 0))).encode())
+    return h.hexdigest()[:16]
+
+
+def minority_tail(p_minority, k_observed):
+    """P(X >= k_observed) for X = number of chains on a minority branch when chain i is there with probability p_minority[i] (the reference's own
+    minority share, independent chains): Poisson-binomial, by dynamic programming."""
+    dist = [1.0]
+    for p in p_minority:
+        nxt = [0.0] * (len(dist) + 1)
+        for k, q in enumerate(dist):
+            nxt[k] += q * (1.0 - p)
+            nxt[k + 1] += q * p
+        dist = nxt
+    return float(sum(dist[k_observed:]))
+
+
 def engine_args(case_in):
     """Golden-case input -> keyword arguments of misti_amd.engine.MigrationInference."""
     i = case_in

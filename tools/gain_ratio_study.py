@@ -73,3 +73,11 @@ for i in range(len(bases) - 1):
         return max(abs(J[0][0]*fb[0] + J[1][0]*fb[1]), abs(J[0][1]*fb[0] + J[1][1]*fb[1]))
     g64 = gn(fb, fa, fc, xb, xa, xc); gex = gn(fbe, fae, fce, [mp.mpf(v) for v in xb], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc])
     print('it', i, 'x (%.4f, %.4f)' % xb, 'ratio f64 %.6f exact %.6f' % (r64, float(rex)), ' g_norm f64 %.4e exact %.4e' % (g64, float(gex)))
+# the point the solve stopped at (its gradient test fired, or the budget ended): the gradient norm alone, float64 against exact
+(xb, fb), (xa, fa), (xc, fc) = bases[-1]
+fbe, fae, fce = f_exact(xb), f_exact(xa), f_exact(xc)
+def gn_last(fb, fa, fc, xb, xa, xc):
+    J = [[(fa[0]-fb[0])/(xa[0]-xb[0]), (fc[0]-fb[0])/(xc[1]-xb[1])], [(fa[1]-fb[1])/(xa[0]-xb[0]), (fc[1]-fb[1])/(xc[1]-xb[1])]]
+    return [J[0][0]*fb[0] + J[1][0]*fb[1], J[0][1]*fb[0] + J[1][1]*fb[1]]
+g64 = gn_last(fb, fa, fc, xb, xa, xc); gex = gn_last(fbe, fae, fce, [mp.mpf(v) for v in xb], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc])
+print('last it', len(bases) - 1, 'x (%.4f, %.4f)' % xb, ' g f64 (%.4e, %.4e) exact (%.4e, %.4e)   [stop when max |g| < 1e-10]' % (g64[0], g64[1], float(gex[0]), float(gex[1])))

@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import load_golden                                   # noqa: E402
-from parity import SELF_FACTOR, engine_args, internal_of, llk_tol, spread_of, status_flips_wide, wide_of    # noqa: E402
+from parity import SELF_FACTOR, branch_of, chain_key, engine_args, internal_of, llk_tol, minority_tail, spread_of, status_flips_wide, wide_of    # noqa: E402
 from misti_amd.engine import MigrationInference                    # noqa: E402
 
 
@@ -29,6 +29,7 @@ def main():
     n_tight = n_self = n_int = n_wide = n_out = n_fail_ok = n_fail_bad = 0
     worst_factor = worst_int = worst_wide = 0.0
     factors = []
+    branches = {}          # chain key -> [(case, branch record, clause)]
     files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["golden_small", "golden_synthetic", "golden_sweep", "golden_campaign", "golden_fullsize", "golden_default_fit",
                                                                     "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample", "golden_config2b", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"]
     for f in files:
@@ -46,7 +47,7 @@ def main():
                 n_fail_ok += ok
                 n_fail_bad += not ok
                 rows.append((c["name"], "ref -inf" if o["llh"] is None else "%.6g" % o["llh"], "hip -inf" if llh == -np.inf else "%.6g" % llh,
-                             "", "", "", "", "", "", "both fail" if both else ("reference flips" if flips else ("reference flips at 2^-40 ... 2^-32" if wide_flip else "MISMATCH"))))
+                             "", "", "", "", "", "", "", "both fail" if both else ("reference flips" if flips else ("reference flips at 2^-40 ... 2^-32" if wide_flip else "MISMATCH"))))
                 continue
             err = abs(llh - o["llh"]) / abs(o["llh"])
             tol = llk_tol(o["llh"], c["in"]["sfs"], o["JAFS"], bool(kw.get("unfolded"))) / abs(o["llh"])
@@ -75,12 +76,22 @@ def main():
             else:
                 cls, factor = "OUTSIDE", "%.2f" % (err / max(spread or 0.0, internal or 0.0)) if (spread or internal) else "inf"
                 n_out += 1
+            # which branch of the reference's own runs the device is on (tests/parity.py: branch_of): "maj 61/64" = the branch 61 of its 64 finite
+            # runs are on; "min 3/64" = a minority branch; "none" = on no branch of the reference; "1 mode" = the reference's runs are not bimodal
+            b = branch_of(o, llh)
+            if b is None:
+                br = "-"
+            elif b["n_modes"] < 2:
+                br = "1 mode" if b["mode"] == 0 else "1 mode, off it"
+            else:
+                br = "none/%d modes" % b["n_modes"] if b["mode"] is None else "%s %d/%d" % ("maj" if b["mode"] == 0 else "min", round(b["share"] * b["runs"]), b["runs"])
+                branches.setdefault(chain_key(c), []).append((c["name"], b, cls))
             rows.append((c["name"], "%.2e" % err, "%.2e" % tol, "%.2e" % spread if spread is not None else "-", "%.2e" % internal if internal is not None else "-", factor,
-                         "%.1e" % ej, "%.1e" % el, "%d/%d" % (o.get("pert_fail", 0), len(o.get("pert_llh", []))), cls))
+                         "%.1e" % ej, "%.1e" % el, "%d/%d" % (o.get("pert_fail", 0), len(o.get("pert_llh", []))), br, cls))
     w = max(len(r[0]) for r in rows)
-    print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %s" % (w, "case", "llk rel", "tol 1e-9", "ref spread", "internal", "factor", "JAFS rel", "lc rel", "pfail", "clause"))
+    print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %-14s %s" % (w, "case", "llk rel", "tol 1e-9", "ref spread", "internal", "factor", "JAFS rel", "lc rel", "pfail", "branch", "clause"))
     for r in rows:
-        print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %s" % ((w,) + r))
+        print("%-*s %10s %10s %10s %10s %7s %9s %9s %6s %-14s %s" % ((w,) + r))
     print()
     print("finite on both sides: %d within 1e-9 (+ floor), %d within %g x the reference's own spread under input perturbations (worst factor %.2f),"
           % (n_tight, n_self, SELF_FACTOR, worst_factor))
@@ -93,6 +104,22 @@ def main():
         print("factor used under clause 2 (%d candidates): median %.2f, 90 %% %.2f, 99 %% %.2f, max %.2f; %d within 1 x, %d within 3 x"
               % (len(f), np.quantile(f, 0.5), np.quantile(f, 0.9), np.quantile(f, 0.99), f.max(), int((f <= 1).sum()), int((f <= 3).sum())))
     print("failures: %d agree or are reference flips, %d mismatches" % (n_fail_ok, n_fail_bad))
+    if branches:
+        # the mode-aware reading of clause 2, per CHAIN: members of a chain inherit the flip of one of its solves
+        p_min, on_min, lines = [], 0, []
+        for key, members in sorted(branches.items(), key=lambda kv: kv[1][0][0]):
+            p = float(np.mean([1.0 - b["majority_share"] for _, b, _ in members]))
+            minority = sum(1 for _, b, _ in members if b["mode"] != 0) * 2 >= len(members)
+            p_min.append(p)
+            on_min += minority
+            if minority:
+                lines.append("    chain of %-28s %2d member(s) on a minority branch; the reference's runs are off its majority branch with frequency %.3f there" % (members[0][0], len(members), p))
+        print()
+        print("branches: %d chains whose reference runs are bimodal; the device is on the reference's MAJORITY branch on %d of them, on a minority branch (or none) on %d;"
+              % (len(branches), len(branches) - on_min, on_min))
+        print("    the reference's own runs are off the majority with summed frequency %.1f over those chains: P(at least %d by chance) = %.3g" % (float(np.sum(p_min)), on_min, minority_tail(p_min, on_min)))
+        for l in lines:
+            print(l)
 
 
 if __name__ == "__main__":
