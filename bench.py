@@ -325,7 +325,7 @@ def main():
     import torch
     import torch.distributed as dist
     from misti_amd.dist import chain_shards, env_rank, shard_indices
-    from misti_amd.engine import Engine, truth_spectrum
+    from misti_amd.engine import Engine, Lanes, truth_spectrum
 
     rank, local_rank, world = env_rank()
     if a.gpus != world and world > 1:
@@ -386,11 +386,11 @@ def main():
             A lane issues on its engine's OWN stream (hipStreamCreate inside misti_create): streams created
             one by one map to distinct hardware queues, whereas streams handed out by torch's pool share
             them (measured: ~11 long kernels in flight on 12 own streams against ~6 on 16 pool streams)."""
-            def __init__(self):
-                self.eng = Engine(w.times, w.lh, device=local_rank, **w.engine_kwargs())
-                # what a caller sweeping a grid knows about its own batches: the split times of this workload have no fractional part (the device
-                # verifies it per candidate); config 4's scan has fractional splits and says nothing
-                self.eng.set_hints(integer_splits=bool(np.all(w.split_time == np.floor(w.split_time))))
+            def __init__(self, pool, index):
+                # lane `index` of the library's own pool (misti_create_lanes, include/misti_hip.h: what a C caller uses to reach this rate);
+                # its context is borrowed for the per-lane stream handle and the per-kernel timing of the serial pass
+                self.pool, self.index = pool, index
+                self.eng = pool.engine(index)
                 self.stream = torch.cuda.ExternalStream(self.eng.stream_handle(), device=dev)
                 # multi-GPU: the llk of `bucket` consecutive batches of this lane are gathered by ONE collective (a 32 KB all_gather
                 # per batch is pure latency on xGMI and costs a fifth of the rate); every batch's llk still reaches every rank
@@ -403,8 +403,8 @@ def main():
 
             def step(self):
                 self.llk = self.slots[self.fill]
-                self.eng.evaluate_dev(n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
-                                      self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
+                self.pool.evaluate_dev(self.index, n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
+                                       self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
                 if use_dist:
                     self.fill += 1
                     if self.fill == bucket:
@@ -423,7 +423,6 @@ def main():
             def close(self):
                 self.eng.sync()
                 self.stream = None
-                self.eng.close()
 
         host_issue = [0.0]
 
@@ -456,7 +455,11 @@ def main():
                 dts.append(timed(lanes, k))
             return dts
 
-        lanes = [Lane() for i in range(max(1, n_streams))]
+        # what a caller sweeping a grid knows about its own batches: the split times of this workload have no fractional part (the device
+        # verifies it per candidate); config 4's scan has fractional splits and says nothing
+        pool = Lanes(w.times, w.lh, device=local_rank, lanes=max(1, n_streams), **w.engine_kwargs())
+        pool.set_hints(integer_splits=bool(np.all(w.split_time == np.floor(w.split_time))))
+        lanes = [Lane(pool, i) for i in range(pool.n_lanes)]
         # context initialisation, not measurement: the first batch of a context allocates its workspaces (hipMalloc) and
         # learns its launch shape; every lane does that once here so that a short run (K < lanes x a few) times steady state
         for lane in lanes:
@@ -498,10 +501,11 @@ def main():
         else:
             res["chains_per_rank"], res["cands_per_rank"] = [chains_mine], [n]
         if keep:
-            res["lanes"] = lanes
+            res["lanes"], res["pool"] = lanes, pool
         else:
             for lane in lanes:
                 lane.close()
+            pool.close()
         return res
 
     def stored_llk_traffic():

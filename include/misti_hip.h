@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MISTI_ABI_VERSION 5
+#define MISTI_ABI_VERSION 6
 
 /* model flags = keyword arguments of MigrationInference.__init__ (:53-74) */
 #define MISTI_CPFIT     1u   /* cpfit=True    (MiSTI.py --cpfit)            */
@@ -253,6 +253,44 @@ int misti_nm_last_stats(misti_ctx* ctx, int64_t stats[2]);
  * 4 + n_param points SciPy could ask for in an iteration go out as one engine batch and one kernel takes its decisions
  * from the values it would have asked for - one chain latency per iteration instead of three; nfev stays SciPy's count. */
 int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
+
+/* ---- lanes: many batches in flight on ONE device ------------------------------------------------ */
+/* One batch is latency-bound: its longest lambda-correction chain is as sequential as the reference's solver (the 4 096-point headline
+ * grid keeps 64 of the chip's 1 024 SIMDs busy for 1.4 ms), so THROUGHPUT comes from independent batches in flight - the grids of
+ * several data sets or models, the replicates of a bootstrap, the vertices of several optimisers: 3.1e7 evaluations/s on the headline
+ * grid with twenty batches in flight against 2.9e6 one at a time.  A lane is one engine context with its own
+ * non-blocking HIP stream; a misti_lanes object is `n_lanes` of them for one model on one device, so that a caller of the C ABI reaches
+ * the overlapped rate without building the pool itself.  The reference's counterpart is one MigrationInference object per process and
+ * as many processes as cores (MiSTI.py:213-214 under `parallel -j`, README.md:110-115).
+ *   - batches of one lane run in submission order, batches of different lanes overlap on the device;
+ *   - results are bit for bit those of a single context (a batch never depends on what else is in flight);
+ *   - own streams map one to one onto hardware queues, of which the HIP runtime opens GPU_MAX_HW_QUEUES per process (default 4, at
+ *     most 24 usable): unless the variable is already set, loading this library sets it to 24 - the runtime reads it when it
+ *     initialises, i.e. at the process's first HIP call.  A process whose runtime was initialised earlier with fewer queues still
+ *     gets correct results, at a lower overlapped rate.  More than ~22 lanes per process share queues and collapse the rate.
+ * Threading: like a context, a misti_lanes object is used by one host thread at a time. */
+typedef struct misti_lanes misti_lanes;
+int misti_create_lanes(const misti_model_t* model, int device, int n_lanes, misti_lanes** out);   /* 1 <= n_lanes <= MISTI_MAX_LANES */
+int misti_destroy_lanes(misti_lanes* lanes);            /* waits for every lane, then releases everything */
+int misti_lanes_size(misti_lanes* lanes);
+/* The i-th lane's context (borrowed: never misti_destroy it): misti_enable_timing, misti_get_stream, misti_last_diag ... per lane. */
+int misti_lanes_context(misti_lanes* lanes, int i, misti_ctx** ctx);
+int misti_lanes_set_hints(misti_lanes* lanes, uint32_t hints);     /* misti_set_hints on every lane */
+/* misti_eval_batch_dev on one lane; returns when the batch is ISSUED.  `lane` >= 0 names the lane; MISTI_LANE_ANY takes a lane that has
+ * nothing in flight if there is one, else the next in round-robin order.  *lane_used (may be NULL) receives the lane the batch went to.
+ * Every pointer is device memory on the object's device, complete before the call (the lanes' streams are non-blocking: they do not
+ * wait for the null stream); output buffers belong to the batch until its lane has been waited for, and a lane's NEXT batch may reuse
+ * them only if the caller is done with the previous results (batches of a lane are ordered, so the device side is safe either way). */
+#define MISTI_LANE_ANY (-1)
+#define MISTI_MAX_LANES 64
+int misti_lanes_eval_batch_dev(misti_lanes* lanes, int lane, int64_t n_cand,
+                               const double* d_split_time, const double* d_params, const int32_t* d_band_bounds,
+                               int64_t n_rep, const double* d_jsfs,
+                               double* d_llk, double* d_jafs, double* d_lc, double* d_pr, int32_t* d_status, int* lane_used);
+int misti_lanes_wait(misti_lanes* lanes, int lane);     /* everything issued on that lane has finished */
+int misti_lanes_sync(misti_lanes* lanes);               /* ... on every lane */
+/* 1 if the lane has work in flight, 0 if not (never blocks); < 0 on error */
+int misti_lanes_busy(misti_lanes* lanes, int lane);
 
 /* ---- several devices --------------------------------------------------------------------- */
 /* One model on a LIST of devices - 1, 2, 4 or 8 GPUs of a node from ONE process: one engine context and one host thread per

@@ -22,7 +22,8 @@ STATUS_TEXT = {
     6: "Stiff interval: the contour solver (rate x length > 96) did not converge",
 }
 MAX_BANDS, MAX_PULSES, MAX_PARAMS, MAX_NUMT = 8, 8, 16, 255
-ABI_VERSION = 5
+LANE_ANY, MAX_LANES = -1, 64
+ABI_VERSION = 6
 TRACE_MAX_CAND, TRACE_MAX_ITER = 64, 200
 
 
@@ -81,6 +82,16 @@ SYMBOLS = {
     "misti_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_kernel_times": (C.c_int, [C.c_void_p, _PD, C.POINTER(C.c_int64), C.c_int]),
     "misti_tables": (C.c_int, [_PI, _PI]),
+    "misti_create_lanes": (C.c_int, [C.POINTER(Model), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "misti_destroy_lanes": (C.c_int, [C.c_void_p]),
+    "misti_lanes_size": (C.c_int, [C.c_void_p]),
+    "misti_lanes_context": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "misti_lanes_set_hints": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "misti_lanes_eval_batch_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "misti_lanes_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "misti_lanes_sync": (C.c_int, [C.c_void_p]),
+    "misti_lanes_busy": (C.c_int, [C.c_void_p, C.c_int]),
     "misti_create_multi": (C.c_int, [C.POINTER(Model), C.c_int, _PI, C.POINTER(C.c_void_p)]),
     "misti_destroy_multi": (C.c_int, [C.c_void_p]),
     "misti_multi_size": (C.c_int, [C.c_void_p]),

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libmisti_hip.so")
-SOURCES = ["misti_kernels.hip", "misti_nm.hip", "misti_api.cpp", "misti_multi.cpp"]
+SOURCES = ["misti_kernels.hip", "misti_nm.hip", "misti_api.cpp", "misti_multi.cpp", "misti_lanes.cpp"]
 HEADERS = ["misti_device.h", "misti_tables.hpp", "misti_consts.h", os.path.join("..", "..", "include", "misti_hip.h")]
 
 

@@ -65,6 +65,26 @@ def _f64(a, shape=None):
     return a
 
 
+def _model_struct(times, lh, bands, pulses, n_param, cpfit, true_eps, smooth, unfolded, sample_date, mixture_th):
+    """(misti_model_t, objects that must stay alive while it is used) from the constructor arguments Engine / Lanes share."""
+    times = _f64(times)
+    lh = _f64(lh)
+    numT = int(lh.shape[0])
+    if lh.ndim != 2 or lh.shape[1] != 2 or times.shape != (numT - 1,):
+        raise ValueError("times must have numT-1 entries and lh shape [numT][2]")
+    flags = (CPFIT if cpfit else 0) | (TRUE_EPS if true_eps else 0) | (SMOOTH if smooth else 0) | (UNFOLDED if unfolded else 0)
+    bands, pulses = list(bands), list(pulses)
+    b_arr = (_lib.Band * max(1, len(bands)))()
+    for i, (pop, start, end, value, param) in enumerate(bands):
+        b_arr[i] = _lib.Band(int(pop), int(start), int(end), int(param), float(value))
+    p_arr = (_lib.Pulse * max(1, len(pulses)))()
+    for i, (pop, time, value, param) in enumerate(pulses):
+        p_arr[i] = _lib.Pulse(int(pop), int(time), int(param), 0, float(value))
+    m = _lib.Model(numT, int(sample_date), flags, len(bands), len(pulses), int(n_param), float(mixture_th),
+                   times.ctypes.data_as(C.POINTER(C.c_double)), lh.ctypes.data_as(C.POINTER(C.c_double)), b_arr, p_arr)
+    return m, (times, lh, b_arr, p_arr)
+
+
 class Engine:
     """One model on one GPU (``misti_create`` ... ``misti_destroy``).
 
@@ -112,7 +132,7 @@ class Engine:
         if getattr(self, "_ctx", None) is not None and self._ctx:
             # a context belongs to the process that created it: in a child forked later (a worker pool of the caller)
             # the HIP runtime is not usable - a garbage-collected copy of this object there must not call into it
-            if getattr(self, "_pid", None) == os.getpid():
+            if getattr(self, "_pid", None) == os.getpid() and not getattr(self, "_borrowed", False):     # a lane of a Lanes object belongs to it
                 self._lib.misti_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
@@ -288,6 +308,77 @@ class Engine:
         _lib.check(self._lib.misti_kernel_times(self._ctx, ms, n, 1 if reset else 0))
         names = ("correct", "spectrum", "llk")
         return {k: ms[i] for i, k in enumerate(names)}, {k: n[i] for i, k in enumerate(names)}
+
+
+# ------------------------------------------------------------------------------
+class Lanes:
+    """``misti_create_lanes`` ... ``misti_destroy_lanes``: n engine contexts of one model on one device, each with its own non-blocking
+    stream, so that independent batches overlap on the GPU (include/misti_hip.h, "lanes"; the overlapped rate of the headline benchmark).
+    The pool itself lives in the library since round 6 - ``misti_amd.lanes.LanePool`` and ``bench.py`` sit on this class.  Same constructor
+    as ``Engine`` plus ``lanes``.  Device-buffer form only (raw device addresses, asynchronous); results are bit for bit a single
+    context's."""
+
+    def __init__(self, times, lh, bands=(), pulses=(), n_param=0, cpfit=False, true_eps=False, smooth=False,
+                 unfolded=False, sample_date=0, mixture_th=0.0, device=0, lanes=20):
+        self._h = C.c_void_p()
+        self._lib = _lib.load()
+        m, keep = _model_struct(times, lh, bands, pulses, n_param, cpfit, true_eps, smooth, unfolded, sample_date, mixture_th)
+        self.numT, self.n_param, self.n_band, self.device = int(m.numT), int(n_param), int(m.n_band), int(device)
+        h = C.c_void_p()
+        _lib.check(self._lib.misti_create_lanes(C.byref(m), int(device), int(lanes), C.byref(h)))
+        self._h = h
+        self._pid = os.getpid()
+        self.n_lanes = int(self._lib.misti_lanes_size(h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            if getattr(self, "_pid", None) == os.getpid():
+                self._lib.misti_destroy_lanes(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def engine(self, i):
+        """Lane i's context as an ``Engine`` that does NOT own it (timing, stream handle, solver trace, ``last_diag`` per lane)."""
+        ctx = C.c_void_p()
+        _lib.check(self._lib.misti_lanes_context(self._h, int(i), C.byref(ctx)))
+        e = Engine.__new__(Engine)
+        e._lib, e._ctx, e._pid, e._borrowed = self._lib, ctx, self._pid, True
+        e.numT, e.n_param, e.n_band, e.device, e.unfolded = self.numT, self.n_param, self.n_band, self.device, False
+        return e
+
+    def set_hints(self, integer_splits=False):
+        _lib.check(self._lib.misti_lanes_set_hints(self._h, _lib.HINT_INTEGER_SPLITS if integer_splits else 0))
+
+    def evaluate_dev(self, lane, n_cand, d_split, d_params, n_rep, d_jsfs, d_llk, d_jafs=0, d_lc=0, d_pr=0, d_status=0, d_bounds=0):
+        """``misti_lanes_eval_batch_dev``: one batch on lane ``lane`` (``None`` / -1: an idle lane, else round-robin); returns the lane used."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        used = C.c_int(-1)
+        _lib.check(self._lib.misti_lanes_eval_batch_dev(self._h, _lib.LANE_ANY if lane is None else int(lane), int(n_cand), v(d_split), v(d_params), v(d_bounds),
+                                                        int(n_rep), v(d_jsfs), v(d_llk), v(d_jafs), v(d_lc), v(d_pr), v(d_status), C.byref(used)))
+        return int(used.value)
+
+    def wait(self, lane):
+        _lib.check(self._lib.misti_lanes_wait(self._h, int(lane)))
+
+    def busy(self, lane):
+        r = self._lib.misti_lanes_busy(self._h, int(lane))
+        if r < 0:
+            _lib.check(r)
+        return bool(r)
+
+    def sync(self):
+        _lib.check(self._lib.misti_lanes_sync(self._h))
 
 
 # ------------------------------------------------------------------------------

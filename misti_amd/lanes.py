@@ -24,7 +24,7 @@ import numpy as np
 # (no effect if the runtime is already up - then export it before starting Python)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
-from .engine import Engine
+from .engine import Lanes
 
 DEFAULT_LANES = 20          # with 24 hardware queues per process: the null stream and a few spare (bench.py)
 
@@ -51,24 +51,27 @@ class Ticket:
 
 
 class LanePool:
+    """Device tensors in, tickets out, on top of the library's own pool (``misti_create_lanes``: misti_amd.engine.Lanes)."""
+
     def __init__(self, times, lh, bands=(), pulses=(), n_param=0, lanes=DEFAULT_LANES, device=0, **flags):
         import torch
         self._torch = torch
         self.device = torch.device("cuda", int(device))
         self.n_param = int(n_param)
-        self.engines = [Engine(times, lh, bands, pulses, n_param=n_param, device=device, **flags) for _ in range(int(lanes))]
+        self.pool = Lanes(times, lh, bands, pulses, n_param=n_param, device=device, lanes=int(lanes), **flags)
+        self.engines = [self.pool.engine(i) for i in range(self.pool.n_lanes)]          # borrowed contexts (per-lane timing, stream handles)
         self.streams = [torch.cuda.ExternalStream(e.stream_handle(), device=self.device) for e in self.engines]
         self._next = 0
         self._outstanding = []
 
     def close(self):
-        for e in self.engines:
-            e.sync()
-        self._outstanding = []
-        self.streams = []
-        for e in self.engines:
-            e.close()
-        self.engines = []
+        if self.pool is not None:
+            self.pool.sync()
+            self._outstanding = []
+            self.streams = []
+            self.engines = []
+            self.pool.close()
+            self.pool = None
 
     def __enter__(self):
         return self
@@ -91,7 +94,7 @@ class LanePool:
         k = self._next if lane is None else int(lane)
         if lane is None:
             self._next = (self._next + 1) % len(self.engines)
-        eng, stream = self.engines[k], self.streams[k]
+        stream = self.streams[k]
         split = self._dev(split_time, (-1,))
         n = split.numel()
         par = self._dev(params, (n, self.n_param)) if self.n_param else None
@@ -103,8 +106,8 @@ class LanePool:
         ready = t.cuda.Event()
         ready.record(t.cuda.current_stream(self.device))         # inputs (and the allocations above) are ordered on this stream
         stream.wait_event(ready)
-        eng.evaluate_dev(n, split.data_ptr(), par.data_ptr() if par is not None else 0, R, rows.data_ptr() if R else 0,
-                         llk.data_ptr() if R else 0, jafs.data_ptr(), 0, 0, status.data_ptr())
+        self.pool.evaluate_dev(k, n, split.data_ptr(), par.data_ptr() if par is not None else 0, R, rows.data_ptr() if R else 0,
+                               llk.data_ptr() if R else 0, jafs.data_ptr(), 0, 0, status.data_ptr())
         done = t.cuda.Event()
         done.record(stream)
         tk = Ticket(k, llk, jafs, status, done, (split, par, rows))

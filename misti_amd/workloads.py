@@ -272,3 +272,32 @@ def config5(spectrum_fn, n_split=32, n_rate=64, n_pulse=32, first_split=64, true
 
 BUILDERS = {"config1": config1, "config2": config2, "config2x16": config2x16, "config2x2": lambda f: config2x16(f, n_grid=2),
             "config2x4": lambda f: config2x16(f, n_grid=4), "config2x8": lambda f: config2x16(f, n_grid=8), "config3": config3, "config4": config4, "config5": config5}
+
+
+def dump_text(workload, path, spectrum_fn=None, **kw):
+    """Write a workload as the whitespace-separated text file examples/lanes_throughput.c reads (format: its header comment).  `workload` is a
+    Workload or the name of one of the constructors above (then the truth spectrum comes from the engine on device 0 unless spectrum_fn is given)."""
+    if isinstance(workload, str):
+        if spectrum_fn is None:
+            from .engine import truth_spectrum
+            spectrum_fn = lambda *a: truth_spectrum(*a)
+        workload = globals()[workload](spectrum_fn, **kw)
+    w = workload
+    g = lambda v: "%.17g" % float(v)
+    flags = (1 if w.flags.get("cpfit") else 0) | (2 if w.flags.get("true_eps") else 0) | (4 if w.flags.get("smooth") else 0) | (8 if w.flags.get("unfolded") else 0)
+    rows = np.atleast_2d(np.asarray(w.jsfs, dtype=np.float64))
+    out = ["%d %d %d %d %d %d %s" % (w.numT, w.sample_date, flags, len(w.bands), len(w.pulses), w.n_param, g(0.0))]
+    out.append(" ".join(g(t) for t in w.times))
+    out.append(" ".join(g(v) for pair in w.lh for v in pair))
+    for pop, start, end, value, param in w.bands:
+        out.append("%d %d %d %d %s" % (pop, start, end, param, g(value)))
+    for pop, time, value, param in w.pulses:
+        out.append("%d %d %d %s" % (pop, time, param, g(value)))
+    out.append("%d %d" % (w.n_cand, rows.shape[0]))
+    out.append(" ".join(g(s) for s in w.split_time))
+    if w.n_param:
+        out.append(" ".join(g(v) for v in np.asarray(w.params, dtype=np.float64).reshape(-1)))
+    out.append(" ".join(g(v) for v in rows.reshape(-1)))
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    return path

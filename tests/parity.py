@@ -201,6 +201,7 @@ def llk_bound(ref_llk, row, jafs, unfolded, spread, internal=None, wide=None):
 # to the reference's own minority rates (Poisson-binomial tail >= BRANCH_ALPHA).  Chains, not candidates: every member of a chain behind
 # the solve that flips inherits the flip (config2b / 2u / 2f share one chain: same PSMC data, same band, same rate).
 MODE_RTOL = 3e-9           # runs closer than this (relative) are the same branch: 3 x the tolerance of clause 1
+MODE_GAP_SHARE = 0.2       # ... and so are runs closer than a fifth of the whole range of the runs (a continuous spread is one branch)
 BRANCH_ALPHA = 0.05
 
 
@@ -212,14 +213,19 @@ def reference_runs(out):
     return runs
 
 
-def modes_of(values, rtol=MODE_RTOL):
-    """Clusters (sorted lists) of the values: single linkage, neighbours within rtol (relative) belong together; largest cluster first."""
+def modes_of(values, rtol=MODE_RTOL, gap_share=MODE_GAP_SHARE):
+    """Branches of the reference's runs: clusters (sorted lists) under single linkage, where two neighbouring values belong together when
+    they are within rtol (relative) OR within gap_share of the whole range of the runs.  The second condition is what tells a FLIP from
+    CONDITIONING: runs that jump between two or three discrete values (one solve ending a step earlier or later) leave a gap of nearly the
+    whole range and fall into as many clusters; runs spread continuously over their range (a llh with a condition number of 1e8: every run
+    a little different) chain into ONE cluster, however wide.  Largest cluster first."""
     vals = sorted(float(v) for v in values)
     if not vals:
         return []
+    link = gap_share * (vals[-1] - vals[0])
     clusters = [[vals[0]]]
     for v in vals[1:]:
-        if abs(v - clusters[-1][-1]) <= rtol * max(abs(v), 1e-300):
+        if abs(v - clusters[-1][-1]) <= max(rtol * max(abs(v), 1e-300), link):
             clusters[-1].append(v)
         else:
             clusters.append([v])

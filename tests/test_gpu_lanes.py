@@ -36,3 +36,68 @@ def test_python_api_example_recovers_the_true_split():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "bootstrap_scan.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "best split 64.00" in r.stdout and "40 scans on 8 lanes" in r.stdout
+
+
+def test_library_lanes_from_python():
+    """misti_create_lanes (ABI 6) through its binding: explicit lanes and MISTI_LANE_ANY, busy / wait / sync, a borrowed per-lane context -
+    and every batch the bits of a single context."""
+    import torch
+    from misti_amd import workloads
+    from misti_amd._lib import MistiError
+    from misti_amd.engine import Engine, Lanes, truth_spectrum
+    w = workloads.config2(lambda *a: truth_spectrum(*a), n_split=16, n_rate=16, first_split=56)
+    dev = torch.device("cuda", 0)
+    n, R = w.n_cand, 1
+    with Engine(w.times, w.lh, **w.engine_kwargs()) as e:
+        want = [e.evaluate(w.split_time, w.params * (1.0 + 0.03 * k), w.jsfs) for k in range(5)]
+    d_split = torch.as_tensor(w.split_time, device=dev)
+    d_par = [torch.as_tensor(w.params * (1.0 + 0.03 * k), device=dev).contiguous() for k in range(5)]
+    d_rows = torch.as_tensor(w.jsfs, device=dev).contiguous()
+    torch.cuda.synchronize()
+    with Lanes(w.times, w.lh, lanes=4, **w.engine_kwargs()) as pool:
+        assert pool.n_lanes == 4
+        pool.set_hints(integer_splits=True)
+        outs, used = [], []
+        for k in range(40):                                  # ten rounds over four lanes, five different grids, nothing waited for in between
+            llk = torch.empty((n, R), dtype=torch.float64, device=dev)
+            st = torch.empty(n, dtype=torch.int32, device=dev)
+            lane = pool.evaluate_dev(k % 4 if k < 20 else None, n, d_split.data_ptr(), d_par[k % 5].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr(), 0, 0, 0, st.data_ptr())
+            used.append(lane)
+            outs.append((k % 5, llk, st))
+        assert used[:20] == [k % 4 for k in range(20)] and all(0 <= u < 4 for u in used)
+        pool.wait(used[-1])
+        assert not pool.busy(used[-1])
+        pool.sync()
+        assert not any(pool.busy(i) for i in range(4))
+        for g, llk, st in outs:
+            assert np.array_equal(llk.cpu().numpy(), want[g].llk, equal_nan=True) and np.array_equal(st.cpu().numpy(), want[g].status)
+        lane0 = pool.engine(0)                               # borrowed: closing it must not destroy the lane
+        assert lane0.stream_handle() != 0 and lane0.stream_handle() != pool.engine(1).stream_handle()
+        lane0.close()
+        llk = torch.empty((n, R), dtype=torch.float64, device=dev)
+        assert pool.evaluate_dev(0, n, d_split.data_ptr(), d_par[0].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr()) == 0
+        pool.sync()
+        assert np.array_equal(llk.cpu().numpy(), want[0].llk, equal_nan=True)
+        with pytest.raises(MistiError, match="out of range"):
+            pool.evaluate_dev(4, n, d_split.data_ptr(), d_par[0].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr())
+    with pytest.raises(MistiError, match="n_lanes"):
+        Lanes(w.times, w.lh, lanes=65, **w.engine_kwargs())
+
+
+def test_c_example_reaches_the_overlapped_rate(tmp_path):
+    """examples/lanes_throughput.c: the headline grid - 4 096 candidates, numT = 128 - from plain C on twenty lanes inside the
+    library: every lane's table is bit for bit one context's misti_eval_batch, and the rate is the overlapped one (bench.py's `value`; one batch
+    at a time gives 2.9e6).  The floor asserted here is deliberately below the measured 3e7: a shared test box is not a benchmark box."""
+    import subprocess
+    from misti_amd import workloads
+    from test_host_cpu import _build_c_example
+    path = workloads.dump_text("config2", str(tmp_path / "config2.txt"))
+    exe = _build_c_example(tmp_path, "lanes_throughput", hip_runtime=True)
+    r = subprocess.run([exe, path, "20", "400"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(l.split(" = ") for l in r.stdout.splitlines() if " = " in l)
+    from parity import record
+    record("c_lanes_example", evals_per_s=float(out["evals_per_s"]), ms_per_step=float(out["ms_per_step"]))
+    assert out["identical"] == "1" and int(out["candidates"]) == 4096 and int(out["lanes"]) == 20
+    assert float(out["finite"]) > 2000
+    assert float(out["evals_per_s"]) >= 1.5e7, out

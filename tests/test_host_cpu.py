@@ -100,8 +100,8 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.misti_abi_version() == 5 == _lib.ABI_VERSION
-    assert "#define MISTI_ABI_VERSION 5" in hdr
+    assert lib.misti_abi_version() == 6 == _lib.ABI_VERSION
+    assert "#define MISTI_ABI_VERSION 6" in hdr
 
 
 def test_tables_match_oracle_structure():
@@ -183,6 +183,10 @@ def test_header_is_plain_c_and_the_example_links(tmp_path):
     # ... and the device-resident form with the RCCL gather inside the library (ABI 5): links against the HIP runtime for its own buffers
     exe = _build_c_example(tmp_path, "multi_device_gather", hip_runtime=True)
     r = subprocess.run([exe, "0"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+    # ... and the lanes (ABI 6: misti_create_lanes / misti_lanes_eval_batch_dev / misti_lanes_sync)
+    exe = _build_c_example(tmp_path, "lanes_throughput", hip_runtime=True)
+    r = subprocess.run([exe, os.devnull], capture_output=True, text=True)
     assert r.returncode == 2 and "no HIP device" in r.stderr
 
 
