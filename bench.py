@@ -664,7 +664,8 @@ def main():
     # ---- secondary legs (every rank runs them: they contain collectives) -------------------------------------------------
     # A secondary leg must never cost the headline line.  With several ranks a leg that raises on ONE rank only (an out-of-memory on one
     # GPU, a HIP error) leaves the others inside a collective for ever: a watchdog on every rank bounds the legs - when it
-    # expires rank 0 emits the headline line as it stands (the legs marked as timed out) and every rank leaves, exit status 0.
+    # expires rank 0 emits the headline line as it stands (the legs marked as timed out) and every rank leaves with exit status 3: the
+    # measured headline is on stdout, and a launcher can still tell a run that hung in a secondary leg from a clean one.
     extra = {}
     watchdog = None
     if not a.no_extra_legs and world > 1:
@@ -674,7 +675,7 @@ def main():
         def expire():
             if rank == 0:
                 os.write(json_fd, (json.dumps(headline_only) + "\n").encode())
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(EXTRA_LEGS_TIMEOUT_S, expire)
         watchdog.daemon = True
         watchdog.start()

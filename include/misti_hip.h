@@ -365,6 +365,9 @@ int misti_multi_basinhopping(misti_multi* m, int64_t n_start, const double* star
  *     bit 24     noise       default fit: the solve went on past a gradient test (gtol) that its noise-free residual
  *                            satisfied, because the reference's own residual - whose rounding noise is measured on the
  *                            spot - would typically not have satisfied it
+ *     bit 25     stall       default fit: the solve was PREDICTED to stall and the starting point was returned with status 3 - what the
+ *                            reference's noisy iteration does on very short intervals after 14 - 23 evaluations (misti_kernels.hip: the stall rule);
+ *                            nfev is then 1, the evaluations the device actually made
  * for intervals 0..numT (row numT is used only by a fractional split); and, for batches of at most
  * MISTI_TRACE_MAX_CAND candidates, the trial points of the unbounded solves (stretched to the unit
  * interval as the reference does, :293-298), at most MISTI_TRACE_MAX_ITER per interval.
@@ -375,6 +378,7 @@ int misti_multi_basinhopping(misti_multi* m, int64_t n_start, const double* star
  *                                                          shared grid; the interval shortened by a
  *                                                          fractional split is not recorded */
 #define MISTI_TRACE_NOISE_BIT (1 << 24)
+#define MISTI_TRACE_STALL_BIT (1 << 25)
 #define MISTI_TRACE_MAX_CAND 64
 #define MISTI_TRACE_MAX_ITER 200
 int misti_enable_solver_trace(misti_ctx* ctx, int on);

@@ -1498,6 +1498,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
     bool first = false, in_solve = false;
     bool yielded = false;      // packed launch: this chain left at interval t for correct_resume_kernel
     bool noise_go = false;     // default fit: the solve went on past a gradient test its noise-free residual satisfied (ect_noise_continues)
+    bool stalled = false;      // default fit: the stall rule returned the starting point (trace bit MISTI_TRACE_STALL_BIT; nfev stays what was evaluated)
     // speculative slots (one chain per wave only): SPEC_SLOTS x 6 lanes, slot 0 = the point the solver asked for
 #ifndef MISTI_SPEC
 #define MISTI_SPEC 1
@@ -1832,7 +1833,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                     // three evaluations.  In the reference's own traces (tests/golden/*_traces.json.gz: 16 200 two-population default-fit solves
                     // of BASELINE's grids and the held-out grid config2b) EVERY one of the 205 solves with 0.29 W / h >= 2 |J| ended that way, and
                     // none of the 15 000 with 0.29 W / h <= 0.04 |J| (in between: 10 % of 239 at 0.15).  The starting point is what the reference
-                    // returns there, so it is what is returned here: status 3, the median evaluation count.  Its model of W is the one of the
+                    // returns there, so it is what is returned here: status 3 (the reference's xtol), with the trace word saying so - bit
+                    // MISTI_TRACE_STALL_BIT - and nfev = 1, the evaluations actually made (the reference's own count there is 14 - 23; a
+                    // made-up 19 used to stand here: ADVICE r5).  Its model of W is the one of the
                     // noise rule below (eps / (0.7 x 2 min(d0, d1)^2), calibrated in round 3).
                     // (Tried: no stall where one Gauss-Newton step of the noise-free residual leaves the positive quadrant - the reference fails
                     // there on config 3's start 4908 in all of its runs - : config 3 under the default fit then has 41 instead of 40 status
@@ -1841,7 +1844,7 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                     const double wm = (0.5 * LSQ_EPS / 0.7) / (dmin * dmin);
                     const double jmax = fmax(fmax(fabs(Jn[0][0]), fabs(Jn[0][1])), fmax(fabs(Jn[1][0]), fabs(Jn[1][1])));
                     const double hh = fmin(fabs(fd_step(xe[0])), fabs(fd_step(xe[1])));
-                    if (dmin > 0.0 && 0.29 * wm > jmax * hh) { term = 3; nfev = 19; }
+                    if (dmin > 0.0 && 0.29 * wm > jmax * hh) { term = 3; stalled = true; }
                 }
 #endif
             } else {
@@ -1906,8 +1909,9 @@ void correct_body(const DevModel& m, int64_t n_items, const ChainBufs& cb, const
                 in_solve = false;
                 // OptimizeResult.status: the termination test that fired, 1 = gtol, 0 = evaluation budget (trf.py:452-456,556-558)
                 const int code = term != 0 ? term : ((accept && fmax(fabs(g[0]), fabs(g[1])) < LSQ_GTOL) ? 1 : 0);
-                const int32_t went_on = noise_go ? MISTI_TRACE_NOISE_BIT : 0;
+                const int32_t went_on = (noise_go ? MISTI_TRACE_NOISE_BIT : 0) | (stalled ? MISTI_TRACE_STALL_BIT : 0);
                 noise_go = false;
+                stalled = false;
                 const double T = G.T(t);               // re-read (LDS) rather than carried through the solver loop
                 if (uni<GROUP>(!finish_interval(x[0] / T, x[1] / T, solver_word(nfev, code, 3) | went_on))) { active = false; stop = true; }   // :312, :346-348
                 break;

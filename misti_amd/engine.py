@@ -285,7 +285,8 @@ class Engine:
     def solver_trace(self, n_cand, cand=None):
         """Solver trace of the last batch: dict of ``nfev``, ``status``, ``kind`` arrays ``[n_cand][numT+1]``
         (kind 0 none, 1 closed form, 2 bounded TRF, 3 unbounded TRF; status = SciPy's termination code; noise 1 where a
-        default-fit solve went on past a gradient test only the reference's noisy residual would have failed) and, with
+        default-fit solve went on past a gradient test only the reference's noisy residual would have failed; stall 1 where the stall rule returned the
+        starting point: status 3 and nfev 1, the reference needs 14 - 23 evaluations to get nowhere) and, with
         ``cand`` given (batches of at most 64 candidates), ``iterates [numT][200][2]``: the trial points of the
         unbounded solves of that candidate's chain (NaN beyond nfev)."""
         n = int(n_cand)
@@ -293,7 +294,7 @@ class Engine:
         its = np.empty((self.numT, _lib.TRACE_MAX_ITER, 2)) if cand is not None else None
         _lib.check(self._lib.misti_last_solver_trace(self._ctx, n, words.ctypes.data_as(C.c_void_p), int(cand) if cand is not None else 0,
                                                      its.ctypes.data_as(C.c_void_p) if its is not None else None))
-        out = {"nfev": words & 0xffff, "status": (words >> 16) & 15, "kind": (words >> 20) & 15, "noise": (words >> 24) & 1}
+        out = {"nfev": words & 0xffff, "status": (words >> 16) & 15, "kind": (words >> 20) & 15, "noise": (words >> 24) & 1, "stall": (words >> 25) & 1}
         if its is not None:
             out["iterates"] = its
         return out
