@@ -267,6 +267,40 @@ def chain_key(case):
     return h.hexdigest()[:16]
 
 
+def fixed_in_advance_names():
+    """Names of the golden cases that were chosen BEFORE any device result existed - every chain of the held-out grid, the evenly spaced default-fit
+    candidates (256 + the first 48), the README sweep, the small fixtures: the sample the branch statistics may be asserted on.  Every other
+    fixture holds candidates that were studied BECAUSE the device deviated from the checker on them; there "off the reference's majority branch" is
+    what selected the case, and its rate says nothing about the device (reported, never asserted)."""
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    names = set()
+    for f, take in (("golden_config2b_allchains", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
+                    ("golden_small", None), ("golden_synthetic", None)):
+        cases = json.load(open(os.path.join(g, f + ".json")))["cases"]
+        names |= {c["name"] for c in (cases if take is None else cases[:take])}
+    return names
+
+
+def branch_statistics(classified, names):
+    """Per-chain branch statistics over the classified cases {name: (chain key, branch record)} restricted to `names`."""
+    chains = {}
+    for name, (key, b) in classified.items():
+        if name in names and b["n_modes"] >= 2:
+            chains.setdefault(key, []).append((name, b))
+    p_min, on_min, detail = [], 0, []
+    for key, members in chains.items():
+        p = float(np.mean([1.0 - b["majority_share"] for _, b in members]))
+        minority = sum(1 for _, b in members if b["mode"] != 0) * 2 >= len(members)         # on a minority branch, or on none of the reference's
+        p_min.append(p)
+        on_min += minority
+        if minority:
+            detail.append((members[0][0], len(members), round(p, 3)))
+    return dict(bimodal_chains=len(chains), on_minority=int(on_min), expected=float(np.sum(p_min)) if p_min else 0.0, tail=minority_tail(p_min, on_min),
+                tail_low=1.0 - minority_tail(p_min, on_min + 1), detail=detail)
+
+
 def minority_tail(p_minority, k_observed):
     """P(X >= k_observed) for X = number of chains on a minority branch when chain i is there with probability p_minority[i] (the reference's own
     minority share, independent chains): Poisson-binomial, by dynamic programming."""
@@ -364,6 +398,25 @@ def adhoc_workload(times, lh, bands, pulses, n_param, flags, sample_date, split_
 
 
 # ---- measured guards -------------------------------------------------------------------------------------------------------------
+def pinned(ok, what):
+    """A guard on the counts THIS BUILD measured (how many candidates sit within 1e-9, how far a named outlier lies, how often (nfev, status)
+    equal the reference's): a regression alarm, not the contract.  The contract - every value within clause 1 / 2 / 2b of the reference's own
+    runs, every status equal or a reference flip, every first-pass outlier reference-studied - stays an assertion everywhere.  A kernel change
+    that is numerically different but equally accurate moves the reference's coin flips and therefore these counts by construction (VERDICT r5
+    weak point 10, item 6): it must be able to pass the suite.  So a pinned guard that does not hold is RECORDED (MISTI_MEASURE_GUARDS) and warned
+    about, and fails only under MISTI_PIN_MEASURED=1 - the builder's own regression runs (tools/reports_round.sh sets it)."""
+    import os
+    import warnings
+    if ok:
+        return True
+    record("pinned_guard_not_met", what=str(what))
+    if os.environ.get("MISTI_PIN_MEASURED") == "1":
+        raise AssertionError("pinned count not met (MISTI_PIN_MEASURED=1): %s" % (what,))
+    warnings.warn("pinned count of an earlier build not met (a report, not the contract): %s" % (what,), RuntimeWarning)
+    return False
+
+
+
 def record(name, **numbers):
     """With MISTI_MEASURE_GUARDS=<file> set, a test appends the counts its guards are pinned to (one JSON line per test): one
     `pytest -m gpu` run on the GPU box then yields every measured number behind the guards (profiles/rNN_measured_guards.jsonl)."""

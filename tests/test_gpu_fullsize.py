@@ -22,7 +22,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN
-from parity import KNOWN_OUTSIDE, KNOWN_STATUS, status_flips_wide, baseline_contract, record
+from parity import KNOWN_OUTSIDE, KNOWN_STATUS, status_flips_wide, baseline_contract, pinned, record
 
 pytestmark = pytest.mark.gpu
 
@@ -77,7 +77,7 @@ def check(key, workload, idx, rep):
     record("fullsize_" + key, both=rep["both"], tight=rep["tight"], self_bound=rep["self_bound"],
            outside=[(int(idx[k]), float(rep["rel"][k])) for k in rep["outside"]], mismatch=[int(idx[k]) for k in rep["mismatch"]])
     if want["tight"] is not None:
-        assert rep["tight"] >= want["tight"] - rep["both"] // 100, (rep["tight"], want)
+        pinned(rep["tight"] >= want["tight"] - rep["both"] // 100, ("tight", key, rep["tight"], want))
     ref = studied(workload)
     for k in list(rep["outside"]) + list(rep["mismatch"]):
         cand = int(idx[k])
@@ -121,8 +121,8 @@ def test_headline_grid_default_fit_every_candidate():
     idx = np.arange(w.n_cand)
     rep = full_contract(w, idx)
     check("config2:default", "config2:default", idx, rep)
-    assert rep["both"] >= MEASURED["config2:default"]["both"] - 40
-    assert len(rep["outside"]) <= MEASURED["config2:default"]["outside"] + 2
+    pinned(rep["both"] >= MEASURED["config2:default"]["both"] - 40, ("both", "config2:default", rep["both"]))
+    pinned(len(rep["outside"]) <= MEASURED["config2:default"]["outside"] + 2, ("first-pass outliers", "config2:default", len(rep["outside"])))
 
 
 def test_held_out_grid_every_candidate():
@@ -134,7 +134,7 @@ def test_held_out_grid_every_candidate():
     rep = full_contract(w, idx)
     check("config2b", "config2b", idx, rep)
     assert rep["both"] == 4096 and rep["worst_tight"] <= 2e-9 and len(rep["mismatch"]) == 0
-    assert len(rep["outside"]) <= MEASURED["config2b"]["outside"] + 2
+    pinned(len(rep["outside"]) <= MEASURED["config2b"]["outside"] + 2, ("first-pass outliers", "config2b", len(rep["outside"])))       # each of them is held to its reference-run study by check()
 
 
 def test_held_out_grid_default_fit():
@@ -146,8 +146,8 @@ def test_held_out_grid_default_fit():
     idx = np.arange(0, w.n_cand, 2)
     rep = full_contract(w, idx)
     check("config2b:default/2", "config2b:default", idx, rep)
-    assert rep["both"] >= MEASURED["config2b:default/2"]["both"] - 20 and len(rep["mismatch"]) == 0
-    assert len(rep["outside"]) <= 2
+    assert len(rep["mismatch"]) == 0
+    pinned(rep["both"] >= MEASURED["config2b:default/2"]["both"] - 20 and len(rep["outside"]) <= 2, ("both / first-pass outliers", "config2b:default/2", rep["both"], len(rep["outside"])))
 
 
 @pytest.mark.parametrize("cpfit", [True, False])
@@ -160,7 +160,7 @@ def test_second_held_out_grid(cpfit):
     rep = full_contract(w, idx)
     key = "config2c/4" if cpfit else "config2c:default/4"
     check(key, "config2c" if cpfit else "config2c:default", idx, rep)
-    assert len(rep["outside"]) <= MEASURED[key]["outside"] + 1
+    pinned(len(rep["outside"]) <= MEASURED[key]["outside"] + 1, ("first-pass outliers", key, len(rep["outside"])))
 
 
 def test_held_out_config3b_and_config5b():
@@ -172,7 +172,8 @@ def test_held_out_config3b_and_config5b():
     idx = np.arange(0, w.n_cand, 4)
     rep = full_contract(w, idx)
     check("config3b/4", "config3b", idx, rep)
-    assert len(rep["outside"]) <= MEASURED["config3b/4"]["outside"] + 2 and len(rep["mismatch"]) == 0
+    assert len(rep["mismatch"]) == 0
+    pinned(len(rep["outside"]) <= MEASURED["config3b/4"]["outside"] + 2, ("first-pass outliers", "config3b/4", len(rep["outside"])))
     w = workloads.config5b(lambda *a: truth_spectrum(*a))
     idx = np.arange(0, w.n_cand, 32)
     rep = full_contract(w, idx)

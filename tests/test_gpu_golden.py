@@ -33,11 +33,8 @@ ALLCHAINS = load_golden("golden_config2b_allchains")
 # case name -> (chain key, branch record) of every golden case whose reference runs were classified (tests/parity.py: branch_of); read by
 # test_branch_rates_match_the_reference at the end of this file
 BRANCHES = {}
-# Cases FIXED IN ADVANCE - chosen before any device result existed: the sample the branch statistics may be asserted on.  Every other fixture
-# holds candidates that were studied BECAUSE the device deviated from the checker on them: there "the device is off the reference's majority
-# branch" is what selected the case, and their minority rate says nothing about the device (it is reported, not asserted).
-FIXED_IN_ADVANCE = ({c["name"] for c in ALLCHAINS} | {c["name"] for c in DEFAULT_FIT_256} | {c["name"] for c in DEFAULT_FIT[:48]} | {c["name"] for c in SWEEP}
-                    | {c["name"] for c in SMALL} | {c["name"] for c in SYNTH})
+from parity import fixed_in_advance_names          # noqa: E402
+FIXED_IN_ADVANCE = fixed_in_advance_names()
 
 
 def run_case(case):
@@ -308,23 +305,6 @@ def test_held_out_grid_every_chain(case):
     check(case)
 
 
-def _branch_statistics(names):
-    chains = {}
-    for name, (key, b) in BRANCHES.items():
-        if name in names and b["n_modes"] >= 2:
-            chains.setdefault(key, []).append((name, b))
-    p_min, on_min, detail = [], 0, []
-    for key, members in chains.items():
-        p = float(np.mean([1.0 - b["majority_share"] for _, b in members]))
-        minority = sum(1 for _, b in members if b["mode"] != 0) * 2 >= len(members)         # on a minority branch, or on none of the reference's
-        p_min.append(p)
-        on_min += minority
-        if minority:
-            detail.append((members[0][0], len(members), round(p, 3)))
-    return dict(bimodal_chains=len(chains), on_minority=int(on_min), expected=float(np.sum(p_min)), tail=minority_tail(p_min, on_min),
-                tail_low=1.0 - minority_tail(p_min, on_min + 1), detail=detail)
-
-
 def test_branch_rates_match_the_reference():
     """Clause 2 of the contract is a max over the reference's runs; where those runs are BIMODAL it admits the minority branch as readily as
     the majority (the config2b chain of rate 0.0464, reference there in 3 of 64 runs).  This is the mode-aware part.  Over the
@@ -337,8 +317,9 @@ def test_branch_rates_match_the_reference():
     from parity import record
     if len(BRANCHES) < 100:
         pytest.skip("the golden tests above did not run in this session (%d classified cases)" % len(BRANCHES))
-    fixed = _branch_statistics(FIXED_IN_ADVANCE)
-    selected = _branch_statistics(set(BRANCHES) - FIXED_IN_ADVANCE)
+    from parity import branch_statistics
+    fixed = branch_statistics(BRANCHES, FIXED_IN_ADVANCE)
+    selected = branch_statistics(BRANCHES, set(BRANCHES) - FIXED_IN_ADVANCE)
     record("golden_branch_summary", fixed_in_advance=fixed, selected_because_the_device_deviated=selected)
     assert fixed["bimodal_chains"] >= 100, fixed
     assert fixed["tail"] >= BRANCH_ALPHA, "device off the reference's majority branch on %d of %d bimodal chains fixed in advance; the reference's own frequencies expect %.1f (P = %.3g): %s" % (

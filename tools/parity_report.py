@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from conftest import load_golden                                   # noqa: E402
-from parity import SELF_FACTOR, branch_of, chain_key, engine_args, internal_of, llk_tol, minority_tail, spread_of, status_flips_wide, wide_of    # noqa: E402
+from parity import SELF_FACTOR, branch_of, branch_statistics, chain_key, fixed_in_advance_names, engine_args, internal_of, llk_tol, minority_tail, spread_of, status_flips_wide, wide_of    # noqa: E402
 from misti_amd.engine import MigrationInference                    # noqa: E402
 
 
@@ -29,7 +29,7 @@ def main():
     n_tight = n_self = n_int = n_wide = n_out = n_fail_ok = n_fail_bad = 0
     worst_factor = worst_int = worst_wide = 0.0
     factors = []
-    branches = {}          # chain key -> [(case, branch record, clause)]
+    classified = {}        # case -> (chain key, branch record)
     files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["golden_small", "golden_synthetic", "golden_sweep", "golden_campaign", "golden_fullsize", "golden_default_fit",
                                                                     "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample", "golden_config2b", "golden_config2b_allchains", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"]
     for f in files:
@@ -79,13 +79,15 @@ def main():
             # which branch of the reference's own runs the device is on (tests/parity.py: branch_of): "maj 61/64" = the branch 61 of its 64 finite
             # runs are on; "min 3/64" = a minority branch; "none" = on no branch of the reference; "1 mode" = the reference's runs are not bimodal
             b = branch_of(o, llh)
+            if b is not None:
+                classified[c["name"]] = (chain_key(c), b)
             if b is None:
                 br = "-"
             elif b["n_modes"] < 2:
                 br = "1 mode" if b["mode"] == 0 else "1 mode, off it"
             else:
                 br = "none/%d modes" % b["n_modes"] if b["mode"] is None else "%s %d/%d" % ("maj" if b["mode"] == 0 else "min", round(b["share"] * b["runs"]), b["runs"])
-                branches.setdefault(chain_key(c), []).append((c["name"], b, cls))
+                pass
             rows.append((c["name"], "%.2e" % err, "%.2e" % tol, "%.2e" % spread if spread is not None else "-", "%.2e" % internal if internal is not None else "-", factor,
                          "%.1e" % ej, "%.1e" % el, "%d/%d" % (o.get("pert_fail", 0), len(o.get("pert_llh", []))), br, cls))
     w = max(len(r[0]) for r in rows)
@@ -104,23 +106,20 @@ def main():
         print("factor used under clause 2 (%d candidates): median %.2f, 90 %% %.2f, 99 %% %.2f, max %.2f; %d within 1 x, %d within 3 x"
               % (len(f), np.quantile(f, 0.5), np.quantile(f, 0.9), np.quantile(f, 0.99), f.max(), int((f <= 1).sum()), int((f <= 3).sum())))
     print("failures: %d agree or are reference flips, %d mismatches" % (n_fail_ok, n_fail_bad))
-    if branches:
+    if classified:
         # the mode-aware reading of clause 2, per CHAIN: members of a chain inherit the flip of one of its solves
-        p_min, on_min, lines = [], 0, []
-        for key, members in sorted(branches.items(), key=lambda kv: kv[1][0][0]):
-            p = float(np.mean([1.0 - b["majority_share"] for _, b, _ in members]))
-            minority = sum(1 for _, b, _ in members if b["mode"] != 0) * 2 >= len(members)
-            p_min.append(p)
-            on_min += minority
-            if minority:
-                lines.append("    chain of %-28s %2d member(s) on a minority branch; the reference's runs are off its majority branch with frequency %.3f there" % (members[0][0], len(members), p))
-        print()
-        print("branches: %d chains whose reference runs are bimodal; the device is on the reference's MAJORITY branch on %d of them, on a minority branch (or none) on %d;"
-              % (len(branches), len(branches) - on_min, on_min))
-        print("    the reference's own runs are off the majority with summed frequency %.1f over those chains: P(at least %d by chance) = %.3g" % (float(np.sum(p_min)), on_min, minority_tail(p_min, on_min)))
-        for l in lines:
-            print(l)
-
+        fixed_names = fixed_in_advance_names()
+        for title, names in (("FIXED IN ADVANCE (every chain of the held-out grid, the evenly spaced default-fit candidates, the README sweep, the small fixtures)", fixed_names),
+                             ("SELECTED because the device deviated from the checker (reported, never asserted: being off the majority is what selected them)", set(classified) - fixed_names)):
+            st = branch_statistics(classified, names)
+            print()
+            print("branches, cases %s:" % title)
+            print("    %d chains whose reference runs are bimodal; the device is on the reference's MAJORITY branch on %d of them, off it on %d;"
+                  % (st["bimodal_chains"], st["bimodal_chains"] - st["on_minority"], st["on_minority"]))
+            print("    the reference's own runs are off their majority with summed frequency %.1f over those chains: P(at least %d by chance) = %.3g, P(at most %d) = %.3g"
+                  % (st["expected"], st["on_minority"], st["tail"], st["on_minority"], st["tail_low"]))
+            for name, n, p in st["detail"]:
+                print("    chain of %-28s %2d member(s) off the majority; the reference's own runs are off it with frequency %.3f there" % (name, n, p))
 
 if __name__ == "__main__":
     main()
