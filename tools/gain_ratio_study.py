@@ -14,8 +14,10 @@ mp.mp.dps = 50
 from misti_amd import workloads
 import oracle.misti_oracle as mo
 from oracle.batch import oracle_eval, oracle_truth_spectrum
-wl = sys.argv[2] if len(sys.argv) > 2 else 'config2'
-w = getattr(workloads, wl)(oracle_truth_spectrum)
+wl = sys.argv[2] if len(sys.argv) > 2 else 'config2'       # config2 | config5 | config5:default (the reference's default fit: the residual of CorrectLambda.py:94-110) ...
+wl_name, _, wl_fit = wl.partition(':')
+DEFAULT_FIT = wl_fit == 'default'
+w = getattr(workloads, wl_name)(oracle_truth_spectrum, **({'cpfit': False} if DEFAULT_FIT else {}))
 c = int(sys.argv[1]) if len(sys.argv) > 1 else 3427
 which = int(sys.argv[3]) if len(sys.argv) > 3 else None
 s, p = float(w.split_time[c]), list(w.params[c])
@@ -33,6 +35,13 @@ class G(mo._PairChain):
         r = super()._residual_cp(l)
         self._log.append((tuple(map(float, l)), tuple(map(float, r))))
         return r
+    def _residual_ect(self, l):
+        if self._n == 0:
+            self._mu_s, self._lh_s, self._log = list(self.mu), list(self.lh), []
+        self._n += 1
+        r = super()._residual_ect(l)
+        self._log.append((tuple(map(float, l)), tuple(map(float, r))))
+        return r
 old = mo._PairChain; mo._PairChain = G
 try:
     oracle_eval(w.times, w.lh, w.bands, w.pulses, w.flags, w.sample_date, s, p, w.jsfs)
@@ -47,6 +56,21 @@ def f_exact(x):
     M = mp.matrix([[-2*mu0 - x[0], 0, mu1], [0, -2*mu1 - x[1], mu0], [2*mu0, 2*mu1, -mu0 - mu1]])
     E = mp.expm(M)
     out = []
+    if DEFAULT_FIT:
+        # LambdaSystem (CorrectLambda.py:151-157,94-110) on the unit interval: conditional expected coalescence time of the pair chain minus the
+        # one-population value 1 / lh - 1 / (e^lh - 1) (:74-77)
+        Minv = M ** -1
+        for kk in (0, 1):
+            s_ = sum(mp.mpf(q) for q in P0[kk])
+            pn = mp.matrix([mp.mpf(q) / s_ for q in P0[kk]])
+            vec1 = Minv * (Minv * ((E - mp.eye(3)) * pn))
+            vec2 = E * pn
+            pnc = sum(vec2)
+            vec2 = Minv * vec2
+            ect2 = (x[0] * (vec2[0] - vec1[0]) + x[1] * (vec2[1] - vec1[1])) / (1 - pnc)
+            lam = mp.mpf(lh[kk])
+            out.append(ect2 - (1 / lam - 1 / (mp.e ** lam - 1)))
+        return out
     for kk in (0, 1):
         v = E * mp.matrix(P0[kk])
         out.append(sum(v) - mp.e ** (-mp.mpf(lh[kk])) * sum(mp.mpf(q) for q in P0[kk]))
@@ -81,3 +105,12 @@ def gn_last(fb, fa, fc, xb, xa, xc):
     return [J[0][0]*fb[0] + J[1][0]*fb[1], J[0][1]*fb[0] + J[1][1]*fb[1]]
 g64 = gn_last(fb, fa, fc, xb, xa, xc); gex = gn_last(fbe, fae, fce, [mp.mpf(v) for v in xb], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc])
 print('last it', len(bases) - 1, 'x (%.4f, %.4f)' % xb, ' g f64 (%.4e, %.4e) exact (%.4e, %.4e)   [stop when max |g| < 1e-10]' % (g64[0], g64[1], float(gex[0]), float(gex[1])))
+# MISTI_STUDY_POINT="x0,x1": the gradient an exact forward-difference Jacobian gives at ANOTHER point (e.g. the device's iterate of the same step,
+# from tools/trace_candidate.py): is a different decision there a different ARITHMETIC or just a different POINT?
+pt = os.environ.get("MISTI_STUDY_POINT")
+if pt:
+    x = tuple(float(v) for v in pt.split(","))
+    h = [1.4901161193847656e-08 * max(1.0, abs(v)) for v in x]
+    xa, xc = (x[0] + h[0], x[1]), (x[0], x[1] + h[1])
+    ge = gn_last(f_exact(x), f_exact(xa), f_exact(xc), [mp.mpf(v) for v in x], [mp.mpf(v) for v in xa], [mp.mpf(v) for v in xc])
+    print('at the point (%.16g, %.16g): exact g (%.4e, %.4e)' % (x[0], x[1], float(ge[0]), float(ge[1])))
