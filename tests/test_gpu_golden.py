@@ -172,7 +172,13 @@ def test_config5_default_fit_first_pass_outliers(case):
     WHAT FALLS OUT AT FACTOR 3 and is listed as such: ten - nine of them one chain (rate x length 3 852) - at 3.0 ... 3.3 x the
     reference's own spread (seven) and 5.8 ... 5.9 x (three); on seven of the ten the reference itself reports "Lambda correction failed" in 8 ... 16 of
     its 16 one-ulp-in-expm runs (its value stands on a knife edge).  Not expected failures and not waved through: those ten are held to ROUND 4's factor
-    of 10 here, explicitly and by name, with the factor recorded; everything else to the contract."""
+    of 10 here, explicitly and by name, with the factor recorded; everything else to the contract.
+    Round 6: the ten are TWO chains (nine members of rate 0.803 / interval 86, one of rate 0.416 / interval 94), traced solve by solve against the
+    reference (tools/trace_goldens.py) - the differing decision is the runaway solve of that interval, reference 28 evaluations, device 24 (41 / 24 on the second chain) -
+    and that solve of the reference evaluated step by step in 50-digit arithmetic (profiles/r06_gain_ratio_config5_default.txt): its own float64 gain ratios are 5.03, 0.22
+    and -3.36 where the exact ones are 0.70, 0.77 and 1.52, and it stops on |J^T f| = 2.9e-11 where the exact value is 9.9e-10.  Its path is set by the rounding error of its
+    expm / inverse in the residual of CorrectLambda.py:94-110; the device's integral series follows exact arithmetic.  Same class as parity.KNOWN_OUTSIDE: not reachable
+    without repeating SciPy's rounding error bit for bit."""
     from parity import SELF_FACTOR, record
     m, llh, _ = run_case(case)
     o = case["out"]
