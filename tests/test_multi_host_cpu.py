@@ -38,3 +38,15 @@ def test_multi_device_host_side_under_sanitizers(tmp_path, rccl_double, sanitize
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "0 failed checks" in r.stdout, r.stdout
     assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
+
+
+def test_lanes_host_side_under_sanitizers(tmp_path):
+    """misti_amd/csrc/misti_lanes.cpp (ABI 6: the pool of contexts behind `misti_create_lanes`) built host-only against stand-ins for the single-context entry
+    points and the HIP event calls (tests/multi_host/lanes_stub_and_driver.cpp), under AddressSanitizer + UBSan: round-robin and "an idle lane first" under
+    MISTI_LANE_ANY, lane bounds, borrowed contexts, a context that fails in the middle of creation (everything made so far is released), no leak over 50 cycles."""
+    exe = str(tmp_path / "lanes_host_driver")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-D__HIP_PLATFORM_AMD__", "-I" + HIP_INCLUDE,
+                    os.path.join(ROOT, "tests", "multi_host", "lanes_stub_and_driver.cpp"), os.path.join(ROOT, "misti_amd", "csrc", "misti_lanes.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "0 failed checks" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "Sanitizer" not in r.stderr, r.stderr[-3000:]
