@@ -206,8 +206,34 @@ struct Diag { bool guard = false; int evals = 0, dense = 0, terms = 0, squarings
 // has no inverse and no cancellation, where the reference's formula loses ~1/|M|^2 digits, and like the exponential it
 // acts on the vector only, so a decoupled component still sees identical arithmetic in every forward-difference lane
 // (the reference's finite-difference Jacobian has an exactly zero entry there; a 3x3 solve by cofactors does not keep it).
+#ifndef MISTI_TAYLOR_LEAN
+#define MISTI_TAYLOR_LEAN 0       // 1: EXPERIMENT (round 6; never the shipped build): Horner form of the --cpfit series, see taylor3_horner
+#endif
+#if MISTI_TAYLOR_LEAN
+// exp(M) v by Horner's rule, w <- v + (M w) / k for k = K .. 1: ten fp64 operations per term where the term-by-term form below needs thirteen (no running sum, the
+// reciprocal folded into the update).  Same accuracy class (the truncation bound is the same; rounding a few ulps either way) - and every bit of every evaluation
+// different, which re-draws the reference's coin flips of DESIGN.md section 2: measured as a variant build against the whole suite, not shipped.
+template <int K>
+__device__ __forceinline__ void taylor3_horner(double d0, double d1, double d2, double mu0, double mu1, double v[3]) {
+    const double v0 = v[0], v1 = v[1], v2 = v[2];
+    const double twomu0 = 2.0 * mu0, twomu1 = 2.0 * mu1;
+    double w0 = v0, w1 = v1, w2 = v2;
+#pragma unroll
+    for (int k = K; k >= 1; --k) {
+        const double inv = 1.0 / (double)k;          // a literal after unrolling
+        const double r0 = mu1 * w2 - d0 * w0;
+        const double r1 = mu0 * w2 - d1 * w1;
+        const double r2 = (twomu0 * w0 + twomu1 * w1) - d2 * w2;
+        w0 = fma(r0, inv, v0); w1 = fma(r1, inv, v1); w2 = fma(r2, inv, v2);
+    }
+    v[0] = w0; v[1] = w1; v[2] = w2;
+}
+#endif
 template <int K, bool INT>
 __device__ __forceinline__ void taylor3(double d0, double d1, double d2, double mu0, double mu1, double v[3], Diag& dg, double vint[3]) {
+#if MISTI_TAYLOR_LEAN
+    if (!INT) { taylor3_horner<K>(d0, d1, d2, mu0, mu1, v); return; }
+#endif
     double p0 = v[0], p1 = v[1], p2 = v[2];
     double a0 = p0, a1 = p1, a2 = p2;
     double b0 = 0.5 * p0, b1 = 0.5 * p1, b2 = 0.5 * p2;
@@ -504,6 +530,16 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         // reciprocals.  No shift, no exp(); cancellation is bounded by e^2 ulp, and a decoupled
         // component again sees identical arithmetic in every forward-difference lane.
         const double nn = 2.0 * nbmax;                // >= ||M||_1
+#if MISTI_TAYLOR_LEAN == 2
+        // ... and degrees for nn^K / K! < 1e-17 (one ulp of a state vector of order one is 1.1e-16) instead of 1e-19: one or two terms fewer per class
+        if (nn <= 0.01) taylor3<7, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.04) taylor3<9, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.12) taylor3<11, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.25) taylor3<13, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 0.5) taylor3<15, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else if (nn <= 1.0) taylor3<19, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+        else taylor3<25, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+#else
         if (nn <= 0.01) taylor3<8, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
         else if (nn <= 0.04) taylor3<10, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
         else if (nn <= 0.12) taylor3<12, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
@@ -511,6 +547,7 @@ __device__ __forceinline__ void pair_expv(double l0, double l1, double mu0, doub
         else if (nn <= 0.5) taylor3<17, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
         else if (nn <= 1.0) taylor3<21, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
         else taylor3<27, INT>(d0, d1, d2, mu0, mu1, v, dg, vint);
+#endif
         if (INT) *have_int = true;
         if (!ok) { v[0] = v[1] = v[2] = NAN; }
         return;

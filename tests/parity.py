@@ -268,7 +268,7 @@ def chain_key(case):
 
 
 def fixed_in_advance_names():
-    """Names of the golden cases that were chosen BEFORE any device result existed - every chain of the held-out grid, the evenly spaced default-fit
+    """Names of the golden cases that were chosen BEFORE any device result existed - every chain of the held-out grid, 64 evenly spaced starts of the held-out config 3, the evenly spaced default-fit
     candidates (256 + the first 48), the README sweep, the small fixtures: the sample the branch statistics may be asserted on.  Every other
     fixture holds candidates that were studied BECAUSE the device deviated from the checker on them; there "off the reference's majority branch" is
     what selected the case, and its rate says nothing about the device (reported, never asserted)."""
@@ -276,7 +276,7 @@ def fixed_in_advance_names():
     import os
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     names = set()
-    for f, take in (("golden_config2b_allchains", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
+    for f, take in (("golden_config2b_allchains", None), ("golden_config3b_fixed64", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
                     ("golden_small", None), ("golden_synthetic", None)):
         cases = json.load(open(os.path.join(g, f + ".json")))["cases"]
         names |= {c["name"] for c in (cases if take is None else cases[:take])}

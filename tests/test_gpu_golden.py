@@ -28,6 +28,7 @@ CONFIG2U = load_golden("golden_config2u")
 CONFIG2M = load_golden("golden_config2m")
 CONFIG2F = load_golden("golden_config2f")
 ALLCHAINS = load_golden("golden_config2b_allchains")
+FIXED64 = load_golden("golden_config3b_fixed64")
 
 
 # case name -> (chain key, branch record) of every golden case whose reference runs were classified (tests/parity.py: branch_of); read by
@@ -308,6 +309,15 @@ def test_held_out_grid_every_chain(case):
     any device result - through /root/reference with 64 + 16 + 16 runs each (tests/golden/make_fullsize.py extra --out
     golden_config2b_allchains.json config2b 4032 ... 4095).  The population view of clause 2: 33 of the 64 chains have a reference that is bimodal
     under its own perturbations, with minority frequencies summing to 5.5 chains; the reference's own base run is off its majority on three."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", FIXED64, ids=[c["name"] for c in FIXED64])
+def test_held_out_config3_fixed_starts(case):
+    """Round 6: 64 starts of the held-out instance of BASELINE config 3 (`config3b`: two bands, two-way migration, every start its own chain), evenly spaced and
+    fixed before any device result (`make_fullsize.py extra --out golden_config3b_fixed64.json config3b 128 384 ...`), each through /root/reference with 64 + 16 + 16
+    runs.  What a candidate NOT selected by a deviation looks like there: the reference's own spread is 1e-13 ... 1e-11 on 58 of the 64, six are bimodal with minority
+    frequencies summing to 0.3 chains."""
     check(case)
 
 
