@@ -114,6 +114,9 @@ def parse(argv=None):
                          "misti_amd.dist and gather it; no engine, no measurement - the line says \"data\": \"dry-run\"")
     ap.add_argument("--gather-bucket", type=int, default=8,
                     help="multi-GPU: batches of a lane whose llk share ONE all_gather (fewer, larger collectives: xGMI is latency-bound at 32 KB)")
+    ap.add_argument("--flush-mode", choices=["filled", "each"], default="filled",
+                    help="multi-GPU: how the partly filled buckets are gathered at the end of a region (flush_all): per lane, filled slots only, "
+                         "shallow lanes first | per lane, whole buckets, lane order (until round 6)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES (default: %d)" % HW_QUEUES)
     ap.add_argument("--streams", type=int, default=DEFAULT_STREAMS,
                     help="HIP streams the steps are issued on round-robin: independent batches overlap (1 = strictly serial)")
@@ -410,14 +413,16 @@ def main():
                     if self.fill == bucket:
                         self.flush()
 
-            def flush(self):
+            def flush(self, filled_only=False):
                 """The bucket's collective, issued from the lane's own stream: c10d orders it after the batches (event on this
                 stream), runs it on its communicator stream in host issue order - the same on every rank - and makes this
                 stream wait for it, so the next batch of the lane cannot overwrite a slot early.  (A dedicated communication
-                stream + events per step cost a hardware queue and 15 % of the rate.)  A partly filled bucket is gathered whole."""
+                stream + events per step cost a hardware queue and 15 % of the rate.)  A partly filled bucket is gathered whole
+                unless `filled_only` (the end of a region: flush_all)."""
                 if use_dist and self.fill > 0:
+                    rows = (self.fill if filled_only else bucket) * per
                     with torch.cuda.stream(self.stream):
-                        dist.all_gather_into_tensor(self.gathered, self.slots.view(bucket * per, R))
+                        dist.all_gather_into_tensor(self.gathered[: world * rows], self.slots.view(bucket * per, R)[:rows])
                     self.fill = 0
 
             def close(self):
@@ -426,14 +431,32 @@ def main():
 
         host_issue = [0.0]
 
+        def flush_all(lanes):
+            """What is still in the lanes' buckets at the end of a region: every lane gathers the FILLED slots of its bucket with a
+            collective of its own, lanes with fewer batches first.  (Until round 6: the whole bucket of 8 whatever it held - in the
+            driver's shape, 20 steps on 18 lanes, one or two batches: 8 x and 4 x the bytes over xGMI - and in lane order, which put all
+            eighteen collectives behind lane 0, the lane that is two batches deep: c10d runs them in host order on ONE communicator
+            stream.  `--flush-mode each` is that form.)  ONE grouped collective for all lanes (c10d's coalescing manager, issued from one
+            lane's stream after it waited for the others) was built and measured on one rank with RCCL initialised: 1.37e7 against
+            2.25e7 evals/s in the driver's shape, and 1.06e7 with the same collectives ungrouped - eighteen cross-queue waits cost
+            more than eighteen small collectives (profiles/r06_flush_modes.txt); not kept."""
+            todo = [lane for lane in lanes if lane.fill > 0]
+            if not use_dist or not todo:
+                return
+            if a.flush_mode == "each":
+                for lane in todo:
+                    lane.flush()
+                return
+            for lane in sorted(todo, key=lambda l: l.fill):           # stable sort: the same order on every rank
+                lane.flush(filled_only=True)
+
         def timed(lanes, k):
             """EXACTLY `k` steps issued round-robin on `lanes` between two fences; seconds (max over ranks)."""
             fence()
             t0 = time.perf_counter()
             for i in range(k):
                 lanes[i % len(lanes)].step()
-            for lane in lanes:                           # what is still in a bucket belongs to the timed steps
-                lane.flush()
+            flush_all(lanes)                             # what is still in a bucket belongs to the timed steps
             host_issue[0] = time.perf_counter() - t0
             fence()
             dt = time.perf_counter() - t0
@@ -448,8 +471,7 @@ def main():
             min_seconds (at least once, at most 200 times; every rank takes the same decision: dt is the all-reduced max)."""
             for i in range(wu):
                 lanes[i % len(lanes)].step()
-            for lane in lanes:
-                lane.flush()
+            flush_all(lanes)
             dts = []
             while not dts or (sum(dts) < min_s and len(dts) < 200):
                 dts.append(timed(lanes, k))
