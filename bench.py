@@ -49,17 +49,18 @@ sys.path.insert(0, ROOT)
 
 
 # Lanes (HIP streams with independent batches in flight).  Measured on MI355X / ROCm 7.2: own streams map
-# one-to-one onto hardware queues up to 24 queues per process; one queue more and the driver time-slices
-# them (throughput collapses 2x).  22 lanes is the single-process peak; defaults leave room for the null
-# stream and, with several ranks, for RCCL's and torch's own streams.
+# one-to-one onto hardware queues; the device runs 23 of them beside each other and time-slices from the 24th
+# ACTIVE one on (a burst of twenty batches: 10 ms instead of 2.7 - profiles/r06_hw_queue_cliff.txt), so the runtime
+# is capped at 22 (HW_QUEUES; streams beyond the cap share queues: slower, never the cliff).  Defaults leave room for
+# the null stream and, with several ranks, for RCCL's and torch's own streams.
 # (single rank with RCCL initialised and one all_gather per 8 batches of a lane: 16 lanes 2.76e7, 18 lanes 2.86e7,
 # 20 lanes 2.65e7, 22 lanes 2.80e7 evals/s against 2.97e7 without RCCL -> 18 with several ranks)
-# (round 5, the driver's shape --steps 20 --warmup 5 with RCCL initialised on one rank: 18 lanes 2.38e7, 19 lanes 2.40e7, 20 lanes 0.80e7 whatever
-# GPU_MAX_HW_QUEUES says - RCCL and c10d take the queues between 19 and 24; ONE collective for all lanes' batches instead of one per lane was
-# tried and is slower, 3.18 against 3.71e7 steady on 18 lanes: every lane then waits for the same collective)
+# (round 5, the driver's shape --steps 20 --warmup 5 with RCCL initialised on one rank: 18 lanes 2.38e7, 19 lanes 2.40e7, 20 lanes 0.80e7 with 24 or
+# more queues - RCCL and c10d take the queues between 19 and 24, and the 24th is the cliff; under the cap of 22 (round 6): 18 lanes 2.31e7, 19 lanes
+# 1.91e7, 20 lanes 1.86e7, nothing collapses.  ONE collective for all lanes' batches instead of one per lane was tried and is slower, 3.18 against
+# 3.71e7 steady on 18 lanes: every lane then waits for the same collective)
 DEFAULT_STREAMS = 20 if (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "--force-dist" not in sys.argv) else 18
-HW_QUEUES = 24
-HW_QUEUE_SLACK = 4
+HW_QUEUES = 22                 # the cap misti_lanes.cpp sets (a 24th ACTIVE queue is a cliff: profiles/r06_hw_queue_cliff.txt); --hw-queues overrides it
 
 
 def _early_streams():
@@ -74,7 +75,7 @@ def _early_streams():
                 v = int(a.split("=", 1)[1])
             if v is not None:
                 n, q = (v, q) if name == "--streams" else (n, v)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(q if q else max(HW_QUEUES, n + HW_QUEUE_SLACK)))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(q if q else HW_QUEUES))      # more lanes than queues share queues; never more queues than the cap
 
 
 _early_streams()
@@ -439,7 +440,9 @@ def main():
             stream.  `--flush-mode each` is that form.)  ONE grouped collective for all lanes (c10d's coalescing manager, issued from one
             lane's stream after it waited for the others) was built and measured on one rank with RCCL initialised: 1.37e7 against
             2.25e7 evals/s in the driver's shape, and 1.06e7 with the same collectives ungrouped - eighteen cross-queue waits cost
-            more than eighteen small collectives (profiles/r06_flush_modes.txt); not kept."""
+            more than eighteen small collectives (profiles/r06_flush_modes.txt); not kept.  Nor is the form whose lanes do not wait for
+            their collective (async_op, released behind the fence): + 3.6 % with 24 hardware queues, - 8 % under the cap of 22 (it keeps
+            one more queue busy)."""
             todo = [lane for lane in lanes if lane.fill > 0]
             if not use_dist or not todo:
                 return

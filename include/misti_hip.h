@@ -264,10 +264,12 @@ int misti_nm_last_spec_iterations(misti_ctx* ctx, int64_t* n);
  * as many processes as cores (MiSTI.py:213-214 under `parallel -j`, README.md:110-115).
  *   - batches of one lane run in submission order, batches of different lanes overlap on the device;
  *   - results are bit for bit those of a single context (a batch never depends on what else is in flight);
- *   - own streams map one to one onto hardware queues, of which the HIP runtime opens GPU_MAX_HW_QUEUES per process (default 4, at
- *     most 24 usable): unless the variable is already set, loading this library sets it to 24 - the runtime reads it when it
- *     initialises, i.e. at the process's first HIP call.  A process whose runtime was initialised earlier with fewer queues still
- *     gets correct results, at a lower overlapped rate.  More than ~22 lanes per process share queues and collapse the rate.
+ *   - own streams map one to one onto hardware queues, of which the HIP runtime opens GPU_MAX_HW_QUEUES per process (default 4):
+ *     unless the variable is already set, loading this library sets it to 22 - the runtime reads it when it initialises, i.e. at the
+ *     process's first HIP call.  22 because the device runs 23 queues beside each other and time-slices them from the 24th ACTIVE one
+ *     on (a burst of twenty batches then takes 10 ms instead of 2.7); under the cap, streams beyond it share queues instead - slower
+ *     (their batches serialise), never the cliff.  A process whose runtime was initialised earlier with fewer queues still gets
+ *     correct results, at a lower overlapped rate.
  * Threading: like a context, a misti_lanes object is used by one host thread at a time. */
 typedef struct misti_lanes misti_lanes;
 int misti_create_lanes(const misti_model_t* model, int device, int n_lanes, misti_lanes** out);   /* 1 <= n_lanes <= MISTI_MAX_LANES */

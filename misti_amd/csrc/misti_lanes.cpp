@@ -31,10 +31,15 @@ int faill(int code, const char* fmt, ...) {
 // One hardware queue per lane: the HIP runtime opens GPU_MAX_HW_QUEUES queues per process (default 4) and reads the variable when it
 // initialises - at the process's first HIP call, which for a C caller comes after this library was loaded.  Never overrides a value
 // the user has set; MISTI_KEEP_HW_QUEUES=1 leaves the environment alone.
+// 22, not "as many as possible": the device runs 23 queues beside each other, and with a 24th ACTIVE one a burst of batches takes 10 ms
+// instead of 2.7 (the scheduler starts time-slicing the queues; measured round 6, profiles/r06_hw_queue_cliff.txt: 22 lanes + the null
+// stream 2.9 ms, 23 lanes 10.4 ms when the runtime may open 32).  Capped at 22 the runtime never opens the 24th: streams beyond the cap
+// SHARE queues (24 lanes: 4.3 ms) - and what else a process creates (the null stream, RCCL's and PyTorch's own streams) cannot push a
+// lane pool over the edge.
 __attribute__((constructor)) void misti_lanes_queue_env() {
     const char* keep = std::getenv("MISTI_KEEP_HW_QUEUES");
     if (keep && keep[0] && keep[0] != '0') return;
-    (void)setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    (void)setenv("GPU_MAX_HW_QUEUES", "22", 0);
 }
 
 }  // namespace

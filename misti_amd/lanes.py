@@ -22,11 +22,11 @@ import numpy as np
 
 # the HIP runtime reads this when it initialises: one hardware queue per lane needs more than its default of 4
 # (no effect if the runtime is already up - then export it before starting Python)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "22")       # 22: misti_lanes.cpp says why not more
 
 from .engine import Lanes
 
-DEFAULT_LANES = 20          # with 24 hardware queues per process: the null stream and a few spare (bench.py)
+DEFAULT_LANES = 20          # with 22 hardware queues per process: the null stream and one spare (bench.py)
 
 
 class Ticket:
