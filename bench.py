@@ -59,7 +59,11 @@ sys.path.insert(0, ROOT)
 # more queues - RCCL and c10d take the queues between 19 and 24, and the 24th is the cliff; under the cap of 22 (round 6): 18 lanes 2.31e7, 19 lanes
 # 1.91e7, 20 lanes 1.86e7, nothing collapses.  ONE collective for all lanes' batches instead of one per lane was tried and is slower, 3.18 against
 # 3.71e7 steady on 18 lanes: every lane then waits for the same collective)
-DEFAULT_STREAMS = 20 if (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "--force-dist" not in sys.argv) else 18
+# Several ranks: 17 lanes.  18 fit under the cap on ONE rank with RCCL initialised (18 lanes + the null stream + c10d's communicator stream + two
+# more, RCCL's own = 22), but with a 19th stream the lanes start sharing queues (2.31e7 -> 1.91e7 in the driver's shape), and RCCL between several
+# ranks has never run on this code: 17 lanes leave one queue spare and cost nothing in the driver's shape (20 steps: 2.31e7 with 17 as with 18
+# lanes - two or three lanes two batches deep take the same time; 16 lanes 2.22e7).
+DEFAULT_STREAMS = 20 if (int(os.environ.get("WORLD_SIZE", "1")) <= 1 and "--force-dist" not in sys.argv) else 17
 HW_QUEUES = 22                 # the cap misti_lanes.cpp sets (a 24th ACTIVE queue is a cliff: profiles/r06_hw_queue_cliff.txt); --hw-queues overrides it
 
 

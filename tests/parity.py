@@ -276,7 +276,8 @@ def fixed_in_advance_names():
     import os
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     names = set()
-    for f, take in (("golden_config2b_allchains", None), ("golden_config3b_fixed64", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
+    for f, take in (("golden_config2b_allchains", None), ("golden_config3b_fixed64", None), ("golden_config5b_fixed64", None), ("golden_config5b_default_fixed64", None),
+                    ("golden_config3b_default_fixed64", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
                     ("golden_small", None), ("golden_synthetic", None)):
         cases = json.load(open(os.path.join(g, f + ".json")))["cases"]
         names |= {c["name"] for c in (cases if take is None else cases[:take])}

@@ -29,6 +29,8 @@ CONFIG2M = load_golden("golden_config2m")
 CONFIG2F = load_golden("golden_config2f")
 ALLCHAINS = load_golden("golden_config2b_allchains")
 FIXED64 = load_golden("golden_config3b_fixed64")
+# round 6, second session: the same population view for the held-out instance of config 5 (--cpfit) and for the DEFAULT fit on both held-out instances
+FIXED64_MORE = load_golden("golden_config5b_fixed64") + load_golden("golden_config5b_default_fixed64") + load_golden("golden_config3b_default_fixed64")
 
 
 # case name -> (chain key, branch record) of every golden case whose reference runs were classified (tests/parity.py: branch_of); read by
@@ -318,6 +320,16 @@ def test_held_out_config3_fixed_starts(case):
     fixed before any device result (`make_fullsize.py extra --out golden_config3b_fixed64.json config3b 128 384 ...`), each through /root/reference with 64 + 16 + 16
     runs.  What a candidate NOT selected by a deviation looks like there: the reference's own spread is 1e-13 ... 1e-11 on 58 of the 64, six are bimodal with minority
     frequencies summing to 0.3 chains."""
+    check(case)
+
+
+@pytest.mark.parametrize("case", FIXED64_MORE, ids=[c["name"] for c in FIXED64_MORE])
+def test_held_out_config5_and_default_fit_fixed_candidates(case):
+    """Round 6, second session (DESIGN section 7 named it as the next step): 64 candidates of the held-out instance of BASELINE config 5 (`config5b`: split x rate
+    x pulse grid, ancient sample; evenly spaced over its 65 536 candidates, 512 + 1 024 k) under --cpfit with 64 + 16 + 16 reference runs each, and 64 + 64 under
+    the reference's DEFAULT fit on `config5b` and `config3b` (128 + 256 k of its 16 384 starts) with 16 + 16 runs - every index fixed before any device result
+    (`make_fullsize.py extra --out golden_config5b_fixed64.json config5b 512 1536 ...`, `... golden_config5b_default_fixed64.json config5b:default ...`,
+    `... golden_config3b_default_fixed64.json config3b:default ...`).  They join the sample the branch statistics are asserted on."""
     check(case)
 
 
