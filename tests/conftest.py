@@ -94,8 +94,10 @@ def _wide_spread():
     return json.load(open(p))["cases"] if os.path.exists(p) else {}
 
 
-def load_golden(name):
-    """Cases of tests/golden/<name>.json with the shared grids expanded."""
+def load_golden(name, optional=False):
+    """Cases of tests/golden/<name>.json with the shared grids expanded (`optional`: no such file -> no cases)."""
+    if optional and not os.path.exists(os.path.join(GOLDEN, name + ".json")):
+        return []
     d = json.load(open(os.path.join(GOLDEN, name + ".json")))
     grids = d.get("grids", {})
     noise = _internal_noise()

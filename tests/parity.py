@@ -279,6 +279,8 @@ def fixed_in_advance_names():
     for f, take in (("golden_config2b_allchains", None), ("golden_config3b_fixed64", None), ("golden_config5b_fixed64", None), ("golden_config5b_default_fixed64", None),
                     ("golden_config3b_default_fixed64", None), ("golden_default_fit_256", None), ("golden_default_fit", 48), ("golden_sweep", None),
                     ("golden_small", None), ("golden_synthetic", None)):
+        if not os.path.exists(os.path.join(g, f + ".json")):
+            continue
         cases = json.load(open(os.path.join(g, f + ".json")))["cases"]
         names |= {c["name"] for c in (cases if take is None else cases[:take])}
     return names

@@ -30,7 +30,7 @@ CONFIG2F = load_golden("golden_config2f")
 ALLCHAINS = load_golden("golden_config2b_allchains")
 FIXED64 = load_golden("golden_config3b_fixed64")
 # round 6, second session: the same population view for the held-out instance of config 5 (--cpfit) and for the DEFAULT fit on both held-out instances
-FIXED64_MORE = load_golden("golden_config5b_fixed64") + load_golden("golden_config5b_default_fixed64") + load_golden("golden_config3b_default_fixed64")
+FIXED64_MORE = load_golden("golden_config5b_fixed64") + load_golden("golden_config5b_default_fixed64", optional=True) + load_golden("golden_config3b_default_fixed64", optional=True)
 
 
 # case name -> (chain key, branch record) of every golden case whose reference runs were classified (tests/parity.py: branch_of); read by

@@ -16,7 +16,7 @@ CAMPAIGN = load_golden("golden_campaign")
 # numT = 128 cases run through the reference in round 4 (tests/golden/make_fullsize.py); ~2 s of oracle each: every fourth / eighth one here
 FULLSIZE = load_golden("golden_fullsize")[::4]
 DEFAULT_FIT = load_golden("golden_default_fit")[::8]
-FULLSIZE_R05 = load_golden("golden_fullsize_r05")[::4] + load_golden("golden_config5_default_sample")[::4] + load_golden("golden_config2b")[::4] + load_golden("golden_config2c")[::6] + load_golden("golden_config3b")[::3] + load_golden("golden_config2n255")[::10] + load_golden("golden_config2u")[::6] + load_golden("golden_config2m")[::4] + load_golden("golden_config2f") + load_golden("golden_config2b_allchains")[5::16] + load_golden("golden_config3b_fixed64")[3::16] + load_golden("golden_config5b_fixed64")[5::16] + load_golden("golden_config5b_default_fixed64")[9::32] + load_golden("golden_config3b_default_fixed64")[13::32]
+FULLSIZE_R05 = load_golden("golden_fullsize_r05")[::4] + load_golden("golden_config5_default_sample")[::4] + load_golden("golden_config2b")[::4] + load_golden("golden_config2c")[::6] + load_golden("golden_config3b")[::3] + load_golden("golden_config2n255")[::10] + load_golden("golden_config2u")[::6] + load_golden("golden_config2m")[::4] + load_golden("golden_config2f") + load_golden("golden_config2b_allchains")[5::16] + load_golden("golden_config3b_fixed64")[3::16] + load_golden("golden_config5b_fixed64")[5::16] + load_golden("golden_config5b_default_fixed64", optional=True)[9::32] + load_golden("golden_config3b_default_fixed64", optional=True)[13::32]
 DEFAULT_FIT_256 = load_golden("golden_default_fit_256")[7::16]        # round 5's 256 fixed candidates (configs 2, 3 and 5, default fit): 16 of them here
 # the oracle restates the reference operation by operation on the same SciPy, so
 # agreement is at rounding level; 1e-12 leaves room for a different BLAS build

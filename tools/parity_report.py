@@ -33,7 +33,7 @@ def main():
     files = [a for a in sys.argv[1:] if not a.startswith("-")] or ["golden_small", "golden_synthetic", "golden_sweep", "golden_campaign", "golden_fullsize", "golden_default_fit",
                                                                     "golden_default_fit_256", "golden_fullsize_r05", "golden_config5_default_sample", "golden_config2b", "golden_config2b_allchains", "golden_config3b_fixed64", "golden_config5b_fixed64", "golden_config5b_default_fixed64", "golden_config3b_default_fixed64", "golden_config2c", "golden_config3b", "golden_config2n255", "golden_config2u", "golden_config2m", "golden_config2f"]
     for f in files:
-        for c in load_golden(f):
+        for c in load_golden(f, optional=True):
             o = c["out"]
             args, kw = engine_args(c["in"])
             with contextlib.redirect_stdout(io.StringIO()):
