@@ -170,13 +170,34 @@ int misti_lanes_eval_batch_dev(misti_lanes* L, int lane, int64_t n_cand, const d
     return 0;
 }
 
+// Waiting for a lane = waiting for the EVENT recorded behind its last batch when that batch was issued, then misti_sync.  The event is
+// what makes the difference with many lanes: asked whether a stream is finished (hipStreamSynchronize, hipStreamQuery,
+// hipDeviceSynchronize) the runtime first has to put a marker of its own behind the stream's last kernel and wait for it to come back -
+// one round trip per hardware queue, one queue after the other, 0.02 ms each: twenty lanes report complete 0.25 - 0.36 ms after their
+// last kernel ended.  The event's marker is already in the queue behind the batch; its signal fires when the batch ends, and the
+// stream synchronisation after it finds the queue's last command complete (tools/ub/queue_burst.hip, wait modes 0 / 5 / 3: a burst
+// of twenty batch-shaped streams WITHOUT events 2.09 / 2.03 ms, with them 1.87 ms; profiles/r06_queue_burst.txt).  Every batch of a
+// context has had such an event behind it since round 3 (misti_api.cpp: last_ev), which is why the bench's device-wide fence never paid
+// that price: the bench gains nothing from waiting here first (2.73 against 2.76 - 2.81 ms, run-to-run spread), a caller that
+// waits lane by lane does.
+static int wait_done(misti_lanes* L, size_t i) {
+    if (!L->used[i]) return 0;
+    const hipError_t e = hipEventSynchronize(L->done[i]);
+    if (e != hipSuccess) return faill(MISTI_E_HIP, "hipEventSynchronize on lane %d: %s", (int)i, hipGetErrorString(e));
+    return 0;
+}
+
 int misti_lanes_wait(misti_lanes* L, int lane) {
     if (!L || lane < 0 || lane >= (int)L->ctx.size()) return faill(MISTI_E_ARG, "no such lane");
+    if (int r = wait_done(L, (size_t)lane)) return r;
     return misti_sync(L->ctx[(size_t)lane]);
 }
 
 int misti_lanes_sync(misti_lanes* L) {
     if (!L) return faill(MISTI_E_ARG, "lanes is NULL");
+    (void)hipSetDevice(L->device);
+    for (size_t i = 0; i < L->ctx.size(); ++i)
+        if (int r = wait_done(L, i)) return r;
     for (size_t i = 0; i < L->ctx.size(); ++i)
         if (int r = misti_sync(L->ctx[i])) { const std::string why = misti_last_error(); return faill(r, "lane %d: %s", (int)i, why.c_str()); }
     return 0;

@@ -28,6 +28,8 @@ int main(int argc, char** argv) {
     const int shapes[][2] = {{0, 0}, {1, 1}, {1, 2}};
     // how the burst is waited for: 0 hipDeviceSynchronize; 1 poll hipStreamQuery on every stream, then hipDeviceSynchronize;
     // 2 an event per stream joined on one stream (device-side waits), hipStreamSynchronize of that one, then hipDeviceSynchronize
+    // 3 an event recorded behind each stream's launches AT ISSUE, hipEventSynchronize of every one, then hipDeviceSynchronize
+    // 4 the same events, polled with hipEventQuery;  5 hipStreamSynchronize of every stream, then hipDeviceSynchronize
     const int wait_mode = argc > 2 ? atoi(argv[2]) : 0;
     if (argc > 3) hipSetDeviceFlags(atoi(argv[3]) ? hipDeviceScheduleSpin : hipDeviceScheduleBlockingSync);
     const int use_graph = argc > 4 ? atoi(argv[4]) : 0;      // 1: the launches of a stream are ONE captured graph (hipGraphLaunch per stream)
@@ -64,8 +66,12 @@ int main(int argc, char** argv) {
                     for (int k = 0; k < sh[0]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
                     spin_kernel<<<20, 128, 0, st[i]>>>(ticks, stamps + 2 * i);
                     for (int k = 0; k < sh[1]; ++k) short_kernel<<<256, 128, 0, st[i]>>>(x);
+                    if (wait_mode == 3 || wait_mode == 4) hipEventRecord(evs[i], st[i]);
                 }
                 const auto t1 = std::chrono::steady_clock::now();
+                if (wait_mode == 3) for (int i = 0; i < N; ++i) hipEventSynchronize(evs[i]);
+                if (wait_mode == 4) for (int i = 0; i < N; ++i) while (hipEventQuery(evs[i]) == hipErrorNotReady) {}
+                if (wait_mode == 5) for (int i = 0; i < N; ++i) hipStreamSynchronize(st[i]);
                 if (wait_mode == 1) {
                     for (int i = 0; i < N; ++i) while (hipStreamQuery(st[i]) == hipErrorNotReady) {}
                 } else if (wait_mode == 2) {
@@ -90,9 +96,9 @@ int main(int argc, char** argv) {
                 }
             }
             for (auto g : gx) if (g) hipGraphExecDestroy(g);
-            printf("N=%2d pre=%d post=%d  burst %.3f ms (issue %.0f us; last long kernel ends at %.0f us; final hipDeviceSynchronize %.0f us)  long-kernel starts [us]:",
+            printf("N=%2d pre=%d post=%d  burst %.3f ms (issue %.0f us; last long kernel ends at %.0f us; final hipDeviceSynchronize %.0f us)",
                    N, sh[0], sh[1], best, starts[N + 2], starts[N], starts[N + 1]);
-            for (int i = 0; i < N; ++i) printf(" %.0f", starts[i]);
+            if (argc > 5) { printf("  long-kernel starts [us]:"); for (int i = 0; i < N; ++i) printf(" %.0f", starts[i]); }
             printf("\n");
         }
         for (auto& s : st) hipStreamDestroy(s);
