@@ -677,7 +677,7 @@ def main():
         "metric": metric,
         "value": value, "unit": "llk evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic", "library": {"build_id": _build_id(), "abi": 5},
+        "dtype": "f64", "data": "synthetic", "library": {"build_id": _build_id(), "abi": _abi()},
         "config": {"workload": w.name, "candidates_per_gpu": n, "candidates_total": job_cands, "replicates": R, "numT": w.numT,
                    "batches_in_flight": n_streams, "streams": n_streams,
                    "world_size": group_world, "candidates_per_rank": main_leg["cands_per_rank"], "chains_per_rank": main_leg["chains_per_rank"],
@@ -868,6 +868,11 @@ def main():
 def _build_id():
     from misti_amd import _lib as _mlib
     return _mlib.build_id()
+
+
+def _abi():
+    from misti_amd import _lib as _mlib
+    return int(_mlib.load().misti_abi_version())
 
 
 def roofline_block(workload, world, dom, per_ms, ab, achieved, n):
