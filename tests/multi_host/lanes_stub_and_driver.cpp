@@ -49,6 +49,12 @@ hipError_t hipEventQuery(hipEvent_t e) {
     if (c && c->busy_for > 0) { c->busy_for -= 1; return hipErrorNotReady; }
     return hipSuccess;
 }
+// waiting for a lane's event (misti_lanes_wait / _sync wait for it before the stream): the batch it was recorded behind is then complete
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    misti_ctx* c = reinterpret_cast<FakeEvent*>(e)->owner;
+    if (c) c->busy_for = 0;
+    return hipSuccess;
+}
 hipError_t hipGetLastError(void) { return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub error"; }
