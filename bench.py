@@ -408,11 +408,13 @@ def main():
                 self.llk = self.slots[0]
                 self.jafs = torch.empty((n, 7), dtype=torch.float64, device=dev)
                 self.status = torch.empty(n, dtype=torch.int32, device=dev)
+                # one batch per slot of the bucket, arguments converted once (Lanes.bind_dev: the step is the same library call, 2 us shorter)
+                self.issue = [pool.bind_dev(index, n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
+                                            self.slots[k].data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr()) for k in range(bucket)]
 
             def step(self):
                 self.llk = self.slots[self.fill]
-                self.pool.evaluate_dev(self.index, n, d_split.data_ptr(), d_par.data_ptr() if P else 0, R, d_jsfs.data_ptr(),
-                                       self.llk.data_ptr(), self.jafs.data_ptr(), 0, 0, self.status.data_ptr())
+                self.issue[self.fill]()
                 if use_dist:
                     self.fill += 1
                     if self.fill == bucket:

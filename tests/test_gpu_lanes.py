@@ -78,6 +78,16 @@ def test_library_lanes_from_python():
         assert pool.evaluate_dev(0, n, d_split.data_ptr(), d_par[0].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr()) == 0
         pool.sync()
         assert np.array_equal(llk.cpu().numpy(), want[0].llk, equal_nan=True)
+        # the same call with its arguments converted once (Lanes.bind_dev: what bench.py's steps use), re-issued on fixed buffers
+        llk_b = torch.empty((n, R), dtype=torch.float64, device=dev)
+        st_b = torch.empty(n, dtype=torch.int32, device=dev)
+        issue = pool.bind_dev(2, n, d_split.data_ptr(), d_par[3].data_ptr(), R, d_rows.data_ptr(), llk_b.data_ptr(), 0, 0, 0, st_b.data_ptr())
+        for _ in range(3):
+            issue()
+        pool.wait(2)
+        assert np.array_equal(llk_b.cpu().numpy(), want[3].llk, equal_nan=True) and np.array_equal(st_b.cpu().numpy(), want[3].status)
+        with pytest.raises(MistiError, match="out of range"):
+            pool.bind_dev(4, n, d_split.data_ptr(), d_par[0].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr())()
         with pytest.raises(MistiError, match="out of range"):
             pool.evaluate_dev(4, n, d_split.data_ptr(), d_par[0].data_ptr(), R, d_rows.data_ptr(), llk.data_ptr())
     with pytest.raises(MistiError, match="n_lanes"):
